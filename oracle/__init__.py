@@ -1,0 +1,171 @@
+"""TEST INFRASTRUCTURE — ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product package (ray_tracing_amd) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile liboracle.so with the Makefile next to this file (g++ only, no GPU)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_renderer_create.restype = C.c_void_p
+        L.orc_renderer_create.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                          C.c_void_p, C.c_uint32, C.c_uint32]
+        L.orc_renderer_destroy.argtypes = [C.c_void_p]
+        L.orc_num_leaf_ids.argtypes = [C.c_void_p]
+        L.orc_num_lights.argtypes = [C.c_void_p]
+        L.orc_camera_get.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_render_sums.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                      C.c_void_p, C.c_void_p]
+        L.orc_draw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t]
+        L.orc_first_hit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_camera_rays.argtypes = [C.c_void_p, C.c_float, C.c_void_p]
+        L.orc_ray_color.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_sampler.argtypes = [C.c_int, C.c_size_t, C.c_uint32, C.c_void_p]
+        L.orc_lights_pdf.restype = C.c_float
+        L.orc_lights_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_lights_random.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_void_p]
+        L.orc_cosine_pdf_value.restype = C.c_float
+        L.orc_cosine_pdf_value.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_onb.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_float_to_rgb.restype = C.c_uint8
+        L.orc_float_to_rgb.argtypes = [C.c_float]
+        L.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f3(v):
+    return np.ascontiguousarray(np.asarray(v, dtype=np.float32).reshape(3))
+
+
+def philox(key, ctr):
+    k = np.asarray(key, dtype=np.uint32)
+    c = np.asarray(ctr, dtype=np.uint32)
+    out = np.zeros(4, dtype=np.uint32)
+    lib().orc_philox4x32_10(_p(k), _p(c), _p(out))
+    return out
+
+
+def sampler(which, n, seed=0):
+    out = np.zeros((n, 3), dtype=np.float32)
+    lib().orc_sampler(which, n, seed, _p(out))
+    return out
+
+
+def cosine_pdf_value(w, d):
+    return float(lib().orc_cosine_pdf_value(_p(_f3(w)), _p(_f3(d))))
+
+
+def onb(w):
+    out = np.zeros((3, 3), dtype=np.float32)
+    lib().orc_onb(_p(_f3(w)), _p(out))
+    return out
+
+
+def float_to_rgb(v):
+    return int(lib().orc_float_to_rgb(float(v)))
+
+
+class OracleRenderer:
+    """Renderer::new(width, height, select_scene(name), Camera::select_camera(w/h, name))."""
+
+    def __init__(self, scene, width, height, scene_seed=1, random_num=11, earth_rgba=None):
+        self.width, self.height, self.scene = width, height, scene
+        self._earth = None
+        ep, ew, eh = None, 0, 0
+        if earth_rgba is not None:
+            self._earth = np.ascontiguousarray(earth_rgba, dtype=np.uint8)
+            eh, ew = self._earth.shape[:2]
+            ep = _p(self._earth)
+        self._h = lib().orc_renderer_create(scene.encode(), width, height, scene_seed, random_num, ep, ew, eh)
+        if not self._h:
+            raise RuntimeError(lib().orc_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_renderer_destroy(self._h)
+            self._h = None
+
+    @property
+    def num_leaf_ids(self):
+        return lib().orc_num_leaf_ids(self._h)
+
+    def camera(self):
+        out = np.zeros(21, dtype=np.float32)
+        lib().orc_camera_get(self._h, _p(out))
+        return out
+
+    def render_sums(self, spp_count, max_depth, seed=0, spp_begin=0, threads=None):
+        """Returns (sums[H,W,3] with row 0 = image bottom, counters[4])."""
+        threads = threads or min(os.cpu_count() or 1, 16)
+        sums = np.zeros((self.height, self.width, 3), dtype=np.float32)
+        cnt = np.zeros(4, dtype=np.uint64)
+        rc = lib().orc_render_sums(self._h, spp_begin, spp_count, max_depth, seed, threads, _p(sums), _p(cnt))
+        if rc:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return sums, cnt
+
+    def draw(self, spp, max_depth, seed=0, threads=None):
+        threads = threads or min(os.cpu_count() or 1, 16)
+        frame = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        rc = lib().orc_draw(self._h, spp, max_depth, seed, threads, _p(frame), frame.size)
+        if rc:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return frame
+
+    def camera_rays(self, time=0.5):
+        rays = np.zeros((self.height * self.width, 7), dtype=np.float32)
+        lib().orc_camera_rays(self._h, time, _p(rays))
+        return rays
+
+    def first_hit(self, rays, seed=0, aov=False):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
+        n = rays.shape[0]
+        ids = np.zeros(n, dtype=np.int32)
+        t = np.zeros(n, dtype=np.float32)
+        a = np.zeros((n, 12), dtype=np.float32) if aov else None
+        rc = lib().orc_first_hit(self._h, _p(rays), n, seed, _p(ids), _p(t), _p(a) if aov else None)
+        if rc:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return (ids, t, a) if aov else (ids, t)
+
+    def ray_color(self, rays, sample=0, max_depth=50, seed=0):
+        rays = np.ascontiguousarray(rays, dtype=np.float32).reshape(-1, 7)
+        out = np.zeros((rays.shape[0], 3), dtype=np.float32)
+        rc = lib().orc_ray_color(self._h, _p(rays), rays.shape[0], sample, max_depth, seed, _p(out))
+        if rc:
+            raise RuntimeError(lib().orc_last_error().decode())
+        return out
+
+    def lights_pdf(self, origin, direction):
+        return float(lib().orc_lights_pdf(self._h, _p(_f3(origin)), _p(_f3(direction))))
+
+    def lights_random(self, origin, n, seed=0):
+        out = np.zeros((n, 3), dtype=np.float32)
+        lib().orc_lights_random(self._h, _p(_f3(origin)), n, seed, _p(out))
+        return out
