@@ -1,0 +1,212 @@
+/*
+ * mirt.h — C ABI of libmirt.so, the MI355X (gfx950) path-tracing backend.
+ *
+ * The reference crate (KaminariOS/ray_tracing) has no FFI; its seam for the per-pixel sample loop
+ * is Renderer::new (src/renderer.rs:41) / Renderer::draw (src/renderer.rs:56). The entry points
+ * below are what a Rust `extern "C"` block bound to that seam would declare: the caller flattens
+ * its Scene (src/scene.rs:277-295) into plain arrays once, hands over its Camera fields
+ * (src/camera.rs:5-20), and replaces the body of draw() with render + resolve.
+ *
+ * Conventions: every function returns MIRT_OK (0) or a negative MIRT_ERR_* code and never throws or
+ * aborts across the boundary; mirt_last_error() returns the message of the last failure on that
+ * context (or of the last failed mirt_create when ctx is NULL). One host thread per context at a
+ * time (the reference's `&mut self`); contexts on different devices are independent. All pointers
+ * in descriptors are host pointers unless a field says "device"; the library copies what it needs
+ * during the call and the caller keeps ownership.
+ */
+#ifndef MIRT_H
+#define MIRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIRT_OK 0
+#define MIRT_ERR_INVALID (-1)  /* bad argument or descriptor */
+#define MIRT_ERR_HIP (-2)      /* a HIP runtime call failed */
+#define MIRT_ERR_STATE (-3)    /* call order: no scene / camera / frame yet */
+#define MIRT_ERR_NO_DEVICE (-4)
+
+typedef struct mirt_ctx mirt_ctx;
+
+/* ---- scene description: the flattened form of src/scene.rs `Scene` ------------------------- */
+
+/* Leaf primitives (src/geo.rs). A Cuboid (geo.rs:245) is six rects in the order XY(kmin,kmax),
+ * XZ(kmin,kmax), YZ(kmin,kmax); FlipFace (geo.rs:442) is a flag; Translation(RotationY(x))
+ * (geo.rs:291,332) is an instance index; ConstantMedium (geo.rs:393) refers to a range of
+ * boundary primitives that are not themselves part of the world. */
+enum { MIRT_PRIM_SPHERE = 0, MIRT_PRIM_RECT = 1, MIRT_PRIM_MEDIUM = 2 };
+enum { MIRT_AXIS_XY = 0, MIRT_AXIS_XZ = 1, MIRT_AXIS_YZ = 2 }; /* AlignedAxis, geo.rs:152-167 */
+enum { MIRT_PRIM_FLIP_FACE = 1u, MIRT_PRIM_MOVING = 2u };
+
+typedef struct mirt_prim {
+    uint32_t kind;     /* MIRT_PRIM_* */
+    uint32_t material; /* index into materials; for a medium: its Isotropic phase material */
+    uint32_t instance; /* index into instances; 0 = no transform */
+    uint32_t flags;    /* MIRT_PRIM_FLIP_FACE | MIRT_PRIM_MOVING */
+    /* sphere (geo.rs:14-23) */
+    float center0[3];
+    float radius;
+    float center1[3];
+    float time0, time1;
+    /* rect (geo.rs:168-174): plane coordinate k on the axis' third index, extents on the first
+     * two (c0 = lo, c1 = hi of AxisAlignedRect::new) */
+    uint32_t axis;
+    float k;
+    float lo[2];
+    float hi[2];
+    /* medium (geo.rs:393-397) */
+    uint32_t boundary_first; /* first boundary primitive */
+    uint32_t boundary_count;
+    float neg_inv_density;
+} mirt_prim;
+
+/* Translation(RotationY(obj, degrees), offset): sin/cos of degrees/180*pi (camera.rs:25-27). */
+typedef struct mirt_instance {
+    float sin_theta, cos_theta;
+    float offset[3];
+} mirt_instance;
+
+enum { MIRT_MAT_LAMBERTIAN = 0, MIRT_MAT_METAL = 1, MIRT_MAT_DIELECTRIC = 2, MIRT_MAT_DIFFUSE_LIGHT = 3, MIRT_MAT_ISOTROPIC = 4 };
+typedef struct mirt_material { /* src/material.rs */
+    uint32_t kind;
+    uint32_t texture; /* Lambertian / DiffuseLight / Isotropic */
+    float albedo[3];  /* Metal */
+    float param;      /* Metal: fuzz (already min(fuzz,1)); Dielectric: index of refraction */
+} mirt_material;
+
+enum { MIRT_TEX_SOLID = 0, MIRT_TEX_CHECKER = 1, MIRT_TEX_NOISE = 2, MIRT_TEX_IMAGE = 3 };
+typedef struct mirt_texture { /* src/texture.rs */
+    uint32_t kind;
+    float color[3];  /* Solid colour; Checker `even` */
+    float color2[3]; /* Checker `odd` */
+    float scale;     /* Noise */
+    uint32_t perlin; /* Noise: index into perlins */
+    uint32_t image;  /* Image: index into images */
+} mirt_texture;
+
+typedef struct mirt_perlin { /* src/perlin.rs:8-11 */
+    float grad[256][3];
+    uint8_t perm[3][256];
+} mirt_perlin;
+
+/* Texels exactly as ImageTexture indexes them (texture.rs:93-97): row y = v*h of the image AFTER
+ * the vertical flip of texture.rs:84. width == 0 means "file missing" and yields (0,1,1). */
+typedef struct mirt_image {
+    uint32_t width, height;
+    const uint8_t* rgba;
+} mirt_image;
+
+/* One element of the world list (scene.rs:290), in order. The list semantics of ray.rs:123-133
+ * (of two hits at the same t the later element wins) are kept for MIRT_ENTRY_LIST entries. A
+ * MIRT_ENTRY_BVH entry is the flattened form of BVHNode (aabb.rs:63): the library builds a linear
+ * node array over its objects at upload. Object j of an entry is the `prims_per_object` primitives
+ * starting at first_prim + j*prims_per_object (6 for cuboids, 1 otherwise). `instance` applies to
+ * the whole entry (Translation(RotationY(BVHNode))). */
+enum { MIRT_ENTRY_LIST = 0, MIRT_ENTRY_BVH = 1 };
+typedef struct mirt_entry {
+    uint32_t kind;
+    uint32_t first_prim;
+    uint32_t prim_count;
+    uint32_t prims_per_object;
+    uint32_t instance;
+} mirt_entry;
+
+typedef struct mirt_scene_desc {
+    const mirt_prim* prims;         uint32_t n_prims;
+    const mirt_entry* world;        uint32_t n_world;
+    const uint32_t* lights;         uint32_t n_lights; /* primitive indices of scene.lights (scene.rs:286) */
+    const mirt_material* materials; uint32_t n_materials;
+    const mirt_texture* textures;   uint32_t n_textures;
+    const mirt_perlin* perlins;     uint32_t n_perlins;
+    const mirt_image* images;       uint32_t n_images;
+    const mirt_instance* instances; uint32_t n_instances; /* entry 0 is the identity and is never applied */
+    float background[3];            /* scene.rs:280 */
+} mirt_scene_desc;
+
+/* src/camera.rs:5-20, the fields get_ray (camera.rs:86-94) reads. */
+typedef struct mirt_camera {
+    float origin[3], lower_left_corner[3], horizontal[3], vertical[3], u[3], v[3];
+    float lens_radius, time0, time1;
+} mirt_camera;
+
+typedef struct mirt_ray { float origin[3], direction[3], time; } mirt_ray;
+
+enum { MIRT_KERNEL_AUTO = 0, MIRT_KERNEL_FUSED = 1, MIRT_KERNEL_WAVEFRONT = 2 };
+
+typedef struct mirt_render_params {
+    uint32_t width, height;
+    uint32_t spp_begin;  /* global index of the first sample of this call */
+    uint32_t spp_count;  /* samples per pixel rendered by this call */
+    uint32_t max_depth;  /* Renderer::max_depth, renderer.rs:35 */
+    uint32_t seed;
+    uint32_t jitter;     /* 0 = no pixel jitter (the multisample == 1 case of renderer.rs:175) */
+    uint32_t kernel;     /* MIRT_KERNEL_* */
+} mirt_render_params;
+
+typedef struct mirt_stats {
+    uint64_t samples;      /* primary paths since the last mirt_frame_begin */
+    uint64_t segments;     /* ray segments traced (ray_color levels that reached world.hit) */
+    double kernel_ms;      /* GPU time of the last mirt_render, HIP events on the render stream */
+    uint32_t kernel_launches; /* launches in the last mirt_render */
+    uint32_t kernel_used;  /* MIRT_KERNEL_FUSED or MIRT_KERNEL_WAVEFRONT */
+} mirt_stats;
+
+/* ---- entry points --------------------------------------------------------------------------- */
+
+/* Process start: bind a context to HIP device `device`. */
+int mirt_create(int device, mirt_ctx** out);
+void mirt_destroy(mirt_ctx* ctx);
+const char* mirt_last_error(const mirt_ctx* ctx);
+
+/* Renderer::new's `scene` argument (renderer.rs:41): flatten, build BVHs, upload once. */
+int mirt_scene_upload(mirt_ctx* ctx, const mirt_scene_desc* desc);
+/* Renderer::new's `camera` argument; also the camera swap of renderer.rs:193. */
+int mirt_camera_set(mirt_ctx* ctx, const mirt_camera* cam);
+
+/* Start a frame: size and zero the float4 accumulation buffer (sum r, g, b, sample count) of
+ * width*height pixels, pixel index y*width + x with y = 0 at the image BOTTOM (renderer.rs:97).
+ * accum_device may be a caller-owned DEVICE buffer of width*height*4 floats (e.g. a torch tensor
+ * that a collective will reduce) or NULL for a library-owned one. */
+int mirt_frame_begin(mirt_ctx* ctx, uint32_t width, uint32_t height, float* accum_device);
+
+/* The spp loop of renderer.rs:100-110 for samples [spp_begin, spp_begin+spp_count): each sample
+ * is sanitised (NaN -> 0, +-inf -> 1, renderer.rs:107) and added to the accumulation buffer.
+ * Asynchronous on the context's stream. Sample ranges make progressive refinement and the
+ * multi-GPU split the same call. */
+int mirt_render(mirt_ctx* ctx, const mirt_render_params* p);
+
+/* renderer.rs:109-116 and the row flip of :97: mean, clamp [0,0.999], sqrt, *256, truncate; alpha
+ * 0xff; top row first. frame is a HOST buffer of len == width*height*4 bytes (checked, mirrors the
+ * assert of renderer.rs:65). Blocks until done. */
+int mirt_resolve_rgba8(mirt_ctx* ctx, uint8_t* frame, size_t len);
+/* The same into a DEVICE buffer, asynchronous on the context's stream. */
+int mirt_resolve_rgba8_device(mirt_ctx* ctx, uint8_t* frame_device, size_t len);
+
+/* Copy the accumulation buffer to the host (n == width*height*4 floats). Blocks. */
+int mirt_read_accum(mirt_ctx* ctx, float* rgba, size_t n);
+/* Device address of the accumulation buffer in use. */
+int mirt_accum_device_ptr(mirt_ctx* ctx, float** out);
+
+/* world.hit(ray, 0.001, inf) (renderer.rs:201) for n host rays: leaf primitive index (-1 = miss)
+ * and t. Ray i draws its constant-medium free paths from (pixel = i, sample = 0, bounce = 0).
+ * aov may be NULL or n*12 floats: point 3, normal 3, front_face, u, v, material colour 3. */
+int mirt_first_hit(mirt_ctx* ctx, const mirt_ray* rays, size_t n, uint32_t seed, int32_t* prim_id, float* t, float* aov);
+
+/* ray_color (renderer.rs:197) for n host rays, one un-sanitised sample each: ray i uses
+ * (pixel = i, sample). out = n*3 floats. */
+int mirt_ray_color(mirt_ctx* ctx, const mirt_ray* rays, size_t n, uint32_t sample, uint32_t max_depth, uint32_t seed, float* out);
+
+int mirt_synchronize(mirt_ctx* ctx);
+int mirt_get_stats(mirt_ctx* ctx, mirt_stats* out);
+
+/* Philox4x32-10 block, the generator behind every get_rand() (rand_gen.rs:7). Host-side. */
+void mirt_philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIRT_H */

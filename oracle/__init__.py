@@ -50,6 +50,7 @@ def lib():
         L.orc_onb.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_float_to_rgb.restype = C.c_uint8
         L.orc_float_to_rgb.argtypes = [C.c_float]
+        L.orc_dump_prims.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_philox4x32_10.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -114,6 +115,11 @@ class OracleRenderer:
     @property
     def num_leaf_ids(self):
         return lib().orc_num_leaf_ids(self._h)
+
+    def dump_prims(self):
+        out = np.zeros((self.num_leaf_ids, 12), dtype=np.float32)
+        lib().orc_dump_prims(self._h, _p(out))
+        return out
 
     def camera(self):
         out = np.zeros(21, dtype=np.float32)

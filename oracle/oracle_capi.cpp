@@ -212,4 +212,37 @@ void orc_onb(const float* w, float* uvw9) {
 }
 uint8_t orc_float_to_rgb(float v) { return Renderer::float_to_rgb(v); }
 
+// Leaf primitives in id order, 12 floats each: {kind (0 sphere, 1 rect, 2 medium), ...}
+//   sphere: center0 3, radius, center1 3, moving, time0, time1
+//   rect:   axis, k, lo0, lo1, hi0, hi1, flip-face seen on the way down
+//   medium: neg_inv_density
+// Used to check that an independently written scene builder declares the same scene.
+static void dump_walk(const Hittable* h, bool flip, float* out) {
+    if (auto* s = dynamic_cast<const Sphere*>(h)) {
+        float* o = out + (size_t)s->prim_id * 12;
+        o[0] = 0; o[1] = s->center0.x; o[2] = s->center0.y; o[3] = s->center0.z; o[4] = s->radius;
+        o[5] = s->center1.x; o[6] = s->center1.y; o[7] = s->center1.z; o[8] = s->moving ? 1.f : 0.f; o[9] = s->time0; o[10] = s->time1;
+    } else if (auto* r = dynamic_cast<const AxisAlignedRect*>(h)) {
+        float* o = out + (size_t)r->prim_id * 12;
+        int id[3];
+        axis_indexes(r->axis, id);
+        o[0] = 1; o[1] = (float)(int)r->axis; o[2] = r->k; o[3] = r->p0[id[0]]; o[4] = r->p0[id[1]]; o[5] = r->p1[id[0]]; o[6] = r->p1[id[1]];
+        o[7] = flip ? 1.f : 0.f;
+    } else if (auto* m = dynamic_cast<const ConstantMedium*>(h)) {
+        float* o = out + (size_t)m->prim_id * 12;
+        o[0] = 2; o[1] = m->neg_inv_density;
+        dump_walk(m->boundary.get(), flip, out);
+    } else if (auto* l = dynamic_cast<const HittableList*>(h)) { for (auto& o : l->objects) dump_walk(o.get(), flip, out); }
+    else if (auto* c = dynamic_cast<const Cuboid*>(h)) dump_walk(c->sides.get(), flip, out);
+    else if (auto* t = dynamic_cast<const Translation*>(h)) dump_walk(t->obj.get(), flip, out);
+    else if (auto* ro = dynamic_cast<const RotationY*>(h)) dump_walk(ro->obj.get(), flip, out);
+    else if (auto* f = dynamic_cast<const FlipFace*>(h)) dump_walk(f->obj.get(), !flip, out);
+    else if (auto* b = dynamic_cast<const BVHNode*>(h)) { for (auto& o : b->input_order) dump_walk(o.get(), flip, out); }
+}
+void orc_dump_prims(void* hv, float* out12) {
+    Renderer& r = *static_cast<Handle*>(hv)->r;
+    std::memset(out12, 0, (size_t)r.scene.num_leaf_ids * 12 * sizeof(float));
+    dump_walk(r.scene.world.get(), false, out12);
+}
+
 }  // extern "C"

@@ -1,0 +1,167 @@
+// Host-side flattening of the reference's pointer BVH (aabb.rs:63-135) into a linear array of
+// 64-byte two-child nodes. The tree SHAPE is this library's own (binned surface-area heuristic,
+// median fallback, bounded depth); the reference picks a random axis per node (aabb.rs:73), so no
+// particular shape is part of its behaviour — any conservative hierarchy returns the same closest
+// hit (ties between equal-t leaves aside, which the reference resolves by tree shape too).
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+#include "dev_types.h"
+
+namespace mirt {
+
+struct BuildObject {
+    float lo[3], hi[3];
+    uint32_t first_prim;
+};
+
+class BvhBuilder {
+   public:
+    // max_depth bounds the traversal stack; leaf_max = objects per leaf.
+    BvhBuilder(std::vector<DevBvhNode>& nodes, std::vector<uint32_t>& slots, int max_depth, uint32_t leaf_max)
+        : nodes_(nodes), slots_(slots), max_depth_(max_depth), leaf_max_(leaf_max) {}
+
+    // Returns the index of the root node.
+    uint32_t build(std::vector<BuildObject>& objs) {
+        Ref r = recurse(objs, 0, objs.size(), 1);
+        if (r.n == 0) return r.c;
+        // whole entry fits one leaf: root with a single child
+        uint32_t idx = (uint32_t)nodes_.size();
+        DevBvhNode nd{};
+        set_child(nd, 0, r);
+        nd.c1 = 0xffffffffu;
+        nd.n1 = 0;
+        for (int a = 0; a < 3; ++a) { nd.lo1[a] = INFINITY; nd.hi1[a] = -INFINITY; }
+        nodes_.push_back(nd);
+        return idx;
+    }
+
+   private:
+    struct Ref {
+        uint32_t c, n;
+        float lo[3], hi[3];
+    };
+    std::vector<DevBvhNode>& nodes_;
+    std::vector<uint32_t>& slots_;
+    int max_depth_;
+    uint32_t leaf_max_;
+
+    static void set_child(DevBvhNode& nd, int which, const Ref& r) {
+        float* lo = which ? nd.lo1 : nd.lo0;
+        float* hi = which ? nd.hi1 : nd.hi0;
+        for (int a = 0; a < 3; ++a) { lo[a] = r.lo[a]; hi[a] = r.hi[a]; }
+        (which ? nd.c1 : nd.c0) = r.c;
+        (which ? nd.n1 : nd.n0) = r.n;
+    }
+    static float area(const float* lo, const float* hi) {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return 2.f * (dx * dy + dy * dz + dz * dx);
+    }
+    static int ceil_log2(size_t n) {
+        int l = 0;
+        while (((size_t)1 << l) < n) ++l;
+        return l;
+    }
+
+    Ref recurse(std::vector<BuildObject>& objs, size_t begin, size_t end, int depth) {
+        Ref r;
+        for (int a = 0; a < 3; ++a) { r.lo[a] = INFINITY; r.hi[a] = -INFINITY; }
+        float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (size_t i = begin; i < end; ++i)
+            for (int a = 0; a < 3; ++a) {
+                r.lo[a] = std::min(r.lo[a], objs[i].lo[a]);
+                r.hi[a] = std::max(r.hi[a], objs[i].hi[a]);
+                float c = 0.5f * (objs[i].lo[a] + objs[i].hi[a]);
+                clo[a] = std::min(clo[a], c);
+                chi[a] = std::max(chi[a], c);
+            }
+        size_t n = end - begin;
+        if (n <= leaf_max_) {
+            r.c = (uint32_t)slots_.size();
+            r.n = (uint32_t)n;
+            for (size_t i = begin; i < end; ++i) slots_.push_back(objs[i].first_prim);
+            return r;
+        }
+        size_t mid = begin;
+        bool use_sah = depth + ceil_log2((n + leaf_max_ - 1) / leaf_max_) + 2 < max_depth_;
+        if (use_sah) mid = sah_split(objs, begin, end, clo, chi);
+        if (mid == begin || mid == end) {
+            // median split on the widest centroid axis
+            int ax = 0;
+            for (int a = 1; a < 3; ++a)
+                if (chi[a] - clo[a] > chi[ax] - clo[ax]) ax = a;
+            mid = begin + n / 2;
+            std::nth_element(objs.begin() + begin, objs.begin() + mid, objs.begin() + end,
+                             [ax](const BuildObject& p, const BuildObject& q) { return p.lo[ax] + p.hi[ax] < q.lo[ax] + q.hi[ax]; });
+        }
+        uint32_t idx = (uint32_t)nodes_.size();
+        nodes_.push_back(DevBvhNode{});
+        Ref l = recurse(objs, begin, mid, depth + 1);
+        Ref rr = recurse(objs, mid, end, depth + 1);
+        DevBvhNode nd{};
+        set_child(nd, 0, l);
+        set_child(nd, 1, rr);
+        nodes_[idx] = nd;
+        r.c = idx;
+        r.n = 0;
+        return r;
+    }
+
+    // 16-bin SAH over centroids; returns the partition point or `begin` if no split helps.
+    size_t sah_split(std::vector<BuildObject>& objs, size_t begin, size_t end, const float* clo, const float* chi) {
+        constexpr int B = 16;
+        float best_cost = INFINITY;
+        int best_axis = -1, best_bin = -1;
+        for (int ax = 0; ax < 3; ++ax) {
+            float ext = chi[ax] - clo[ax];
+            if (!(ext > 0.f)) continue;
+            float scale = (float)B / ext;
+            struct Bin { float lo[3], hi[3]; uint32_t n; } bins[B];
+            for (auto& b : bins) { for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; } b.n = 0; }
+            for (size_t i = begin; i < end; ++i) {
+                float c = 0.5f * (objs[i].lo[ax] + objs[i].hi[ax]);
+                int bi = std::min(B - 1, std::max(0, (int)((c - clo[ax]) * scale)));
+                Bin& b = bins[bi];
+                ++b.n;
+                for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], objs[i].lo[a]); b.hi[a] = std::max(b.hi[a], objs[i].hi[a]); }
+            }
+            float la[B], ra[B];
+            uint32_t ln[B], rn[B];
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            uint32_t cnt = 0;
+            for (int i = 0; i < B; ++i) {
+                if (bins[i].n) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], bins[i].lo[a]); hi[a] = std::max(hi[a], bins[i].hi[a]); }
+                cnt += bins[i].n;
+                ln[i] = cnt;
+                la[i] = cnt ? area(lo, hi) : 0.f;
+            }
+            for (int a = 0; a < 3; ++a) { lo[a] = INFINITY; hi[a] = -INFINITY; }
+            cnt = 0;
+            for (int i = B - 1; i >= 0; --i) {
+                if (bins[i].n) for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], bins[i].lo[a]); hi[a] = std::max(hi[a], bins[i].hi[a]); }
+                cnt += bins[i].n;
+                rn[i] = cnt;
+                ra[i] = cnt ? area(lo, hi) : 0.f;
+            }
+            for (int i = 0; i + 1 < B; ++i) {
+                if (ln[i] == 0 || rn[i + 1] == 0) continue;
+                float cost = la[i] * (float)ln[i] + ra[i + 1] * (float)rn[i + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = ax; best_bin = i; }
+            }
+        }
+        if (best_axis < 0) return begin;
+        float scale = (float)B / (chi[best_axis] - clo[best_axis]);
+        float c0 = clo[best_axis];
+        int ax = best_axis, bb = best_bin;
+        auto it = std::partition(objs.begin() + begin, objs.begin() + end, [=](const BuildObject& o) {
+            float c = 0.5f * (o.lo[ax] + o.hi[ax]);
+            int bi = std::min(B - 1, std::max(0, (int)((c - c0) * scale)));
+            return bi <= bb;
+        });
+        return (size_t)(it - objs.begin());
+    }
+};
+
+}  // namespace mirt

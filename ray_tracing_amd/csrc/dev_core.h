@@ -1,0 +1,725 @@
+// Device code of the path tracer: vector math, the Philox draw streams, primitive intersection,
+// list / BVH traversal, hit reconstruction, textures, materials and the light-mixture sampling.
+// Every function states which part of the reference renderer it computes.
+//
+// Template parameter F (a mask of mirt::F_* bits) strips the code a scene does not need, so the
+// Cornell-box kernel carries no BVH stack, medium, Perlin or image-texture code.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_types.h"
+
+namespace mirt {
+
+#define MIRT_DEV __device__ __forceinline__
+#define MIRT_INF __builtin_huge_valf()
+constexpr float kPi = 3.14159265358979323846f;
+
+// ---------------------------------------------------------------------------------------------
+// vector math — same operation order as the reference's nalgebra Vector3<f32>
+// ---------------------------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+MIRT_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+MIRT_DEV V3 v3(const float* p) { return V3{p[0], p[1], p[2]}; }
+MIRT_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MIRT_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MIRT_DEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+MIRT_DEV V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+MIRT_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+MIRT_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+MIRT_DEV V3 cmul(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+MIRT_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+MIRT_DEV float norm_squared(V3 a) { return dot(a, a); }
+MIRT_DEV V3 normalize(V3 a) { return a / sqrtf(norm_squared(a)); }
+MIRT_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+MIRT_DEV float comp(V3 v, uint32_t i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+
+struct Ray {
+    V3 o, d;
+    float time;
+};
+MIRT_DEV V3 ray_at(const Ray& r, float t) { return r.o + t * r.d; }
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 draw streams (stands in for rand::random::<f32>() of rand_gen.rs:7-17)
+//   key = (pixel, sample)   ctr = (block, bounce, stream, seed)
+// draw i of a stream is word (i & 3) of block (i >> 2), mapped to [0,1) as (w >> 8) * 2^-24.
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { STREAM_CAMERA = 0, STREAM_SCATTER = 1, STREAM_MEDIUM = 2 };
+
+MIRT_DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t& o0,
+                            uint32_t& o1, uint32_t& o2, uint32_t& o3) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0;
+        uint64_t p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += W0;
+        k1 += W1;
+    }
+    o0 = c0; o1 = c1; o2 = c2; o3 = c3;
+}
+
+MIRT_DEV float unit_f32(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
+
+struct Rng {
+    uint32_t k0, k1, c1, c2, c3;
+    uint32_t pos;
+    uint32_t w0, w1, w2, w3;
+    MIRT_DEV void init(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stream, uint32_t seed) {
+        k0 = pixel; k1 = sample; c1 = bounce; c2 = stream; c3 = seed; pos = 0;
+    }
+    MIRT_DEV float next() {
+        uint32_t i = pos & 3u;
+        if (i == 0) philox4x32_10(k0, k1, pos >> 2, c1, c2, c3, w0, w1, w2, w3);
+        uint32_t w = i == 0 ? w0 : (i == 1 ? w1 : (i == 2 ? w2 : w3));
+        ++pos;
+        return unit_f32(w);
+    }
+    // rand_gen.rs:20-23
+    MIRT_DEV float range(float mn, float mx) { return mn + (mx - mn) * next(); }
+};
+
+// rand_gen.rs:45-52 — rejection from the cube [-1,1)^3, three draws per trial.
+MIRT_DEV V3 rand_in_unit_sphere(Rng& g) {
+    for (;;) {
+        float x = g.range(-1.f, 1.f);
+        float y = g.range(-1.f, 1.f);
+        float z = g.range(-1.f, 1.f);
+        V3 p = v3(x, y, z);
+        if (norm_squared(p) < 1.f) return p;
+    }
+}
+// rand_gen.rs:70-78 — two draws per trial.
+MIRT_DEV V3 rand_in_unit_disk(Rng& g) {
+    for (;;) {
+        float x = g.range(-1.f, 1.f);
+        float y = g.range(-1.f, 1.f);
+        V3 p = v3(x, y, 0.f);
+        if (norm_squared(p) >= 1.f) continue;
+        return p;
+    }
+}
+// rand_gen.rs:80-90 — r2 in [0, 0.9): z >= sqrt(0.1).
+MIRT_DEV V3 random_cosine_direction(float xi1, float xi2) {
+    float r1 = xi1;
+    float r2 = 0.f + (0.9f - 0.f) * xi2;
+    float z = sqrtf(1.f - r2);
+    float phi = 2.f * kPi * r1;
+    float r2_sq = sqrtf(r2);
+    float sn, cs;
+    sincosf(phi, &sn, &cs);
+    return v3(cs * r2_sq, sn * r2_sq, z);
+}
+
+// onb.rs:38-49 / onb.rs:34-36 — u and v are not normalised.
+struct Onb {
+    V3 u, v, w;
+};
+MIRT_DEV Onb onb_from_w(V3 w) {
+    V3 a = fabsf(w.x) > 0.9f ? v3(0.f, 1.f, 0.f) : v3(1.f, 0.f, 0.f);
+    Onb o;
+    o.v = cross(w, a);
+    o.u = cross(w, o.v);
+    o.w = w;
+    return o;
+}
+MIRT_DEV V3 onb_local(const Onb& o, V3 c) { return (o.u * c.x + o.v * c.y) + o.w * c.z; }
+
+// ---------------------------------------------------------------------------------------------
+// instances: Translation(RotationY(obj)) — geo.rs:306-315, 372-385
+// ---------------------------------------------------------------------------------------------
+MIRT_DEV V3 rot_y(const DevInstance& in, V3 p) {
+    return v3(in.cos_t * p.x + in.sin_t * p.z, p.y, -in.sin_t * p.x + in.cos_t * p.z);
+}
+MIRT_DEV V3 inv_rot_y(const DevInstance& in, V3 p) {
+    return v3(in.cos_t * p.x - in.sin_t * p.z, p.y, in.sin_t * p.x + in.cos_t * p.z);
+}
+MIRT_DEV Ray to_local(const DevInstance& in, const Ray& r) {
+    Ray l;
+    l.o = inv_rot_y(in, r.o - v3(in.ox, in.oy, in.oz));
+    l.d = inv_rot_y(in, r.d);
+    l.time = r.time;
+    return l;
+}
+
+// ---------------------------------------------------------------------------------------------
+// primitives
+// ---------------------------------------------------------------------------------------------
+// geo.rs:62-69
+template <uint32_t F>
+MIRT_DEV V3 sphere_center(const DevPrim& p, float time) {
+    V3 c0 = v3(p.a[0], p.a[1], p.a[2]);
+    if ((F & F_MOVING) && (p.meta & PM_MOVING)) {
+        V3 c1 = v3(p.b[0], p.b[1], p.b[2]);
+        float t0 = p.b[3], t1 = p.c0;
+        return c0 + (time - t0) / (t1 - t0) * (c1 - c0);
+    }
+    return c0;
+}
+
+// geo.rs:89-105 — a = |d|^2; nearest root in [t_min, t_max], both ends inclusive.
+MIRT_DEV bool sphere_hit_c(V3 center, float radius, const Ray& r, float t_min, float t_max, float& t_out) {
+    V3 oc = r.o - center;
+    float a = norm_squared(r.d);
+    float half_b = dot(oc, r.d);
+    float c = norm_squared(oc) - radius * radius;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.f) return false;
+    float sqrtd = sqrtf(discriminant);
+    float root = (-half_b - sqrtd) / a;
+    if (root < t_min || root > t_max) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || root > t_max) return false;
+    }
+    t_out = root;
+    return true;
+}
+
+// geo.rs:160-166
+MIRT_DEV void axis_indexes(uint32_t axis, uint32_t& xi, uint32_t& yi, uint32_t& zi) {
+    xi = axis == 2 ? 1u : 0u;
+    yi = axis == 0 ? 1u : 2u;
+    zi = axis == 0 ? 2u : (axis == 1 ? 1u : 0u);
+}
+
+// geo.rs:196-204 — zero-thickness plane, inclusive range and extent tests.
+MIRT_DEV bool rect_hit(const DevPrim& p, const Ray& r, float t_min, float t_max, float& t_out) {
+    uint32_t xi, yi, zi;
+    axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
+    float k = p.a[0];
+    float t = (k - comp(r.o, zi)) / comp(r.d, zi);
+    if (t < t_min || t > t_max) return false;
+    float x = comp(r.o, xi) + t * comp(r.d, xi);
+    float y = comp(r.o, yi) + t * comp(r.d, yi);
+    if (x < p.a[1] || x > p.a[2] || y < p.a[3] || y > p.b[0]) return false;
+    t_out = t;
+    return true;
+}
+
+template <uint32_t F>
+MIRT_DEV bool leaf_hit(const DevPrim& p, const Ray& r, float t_min, float t_max, float& t_out) {
+    uint32_t kind = p.meta & PM_KIND_MASK;
+    if ((F & F_SPHERE) && (!(F & F_RECT) || kind == PK_SPHERE))
+        return sphere_hit_c(sphere_center<F>(p, r.time), p.a[3], r, t_min, t_max, t_out);
+    if ((F & F_RECT) && kind == PK_RECT) return rect_hit(p, r, t_min, t_max, t_out);
+    return false;
+}
+
+// Where the medium free-path draws of one ray come from.
+struct DrawKey {
+    uint32_t pixel, sample, bounce, seed;
+};
+
+// HittableList::hit (ray.rs:123-133) over prims [first, first+count) whose indices are
+// wave-uniform: `t <= closest` accepts, so the later primitive wins a tie. Sphere / rect only
+// (used for the boundaries of constant media and, through list_scan, for the world).
+template <uint32_t F>
+MIRT_DEV void boundary_scan(const DevScene& s, uint32_t first, uint32_t count, const Ray& r, float t_min, float& closest,
+                            int& best) {
+    uint32_t cur_inst = 0;
+    Ray lr = r;
+    for (uint32_t i = first; i < first + count; ++i) {
+        const DevPrim& p = s.prims[i];
+        if (F & F_INSTANCE) {
+            uint32_t inst = p.instance;
+            if (inst != cur_inst) {
+                cur_inst = inst;
+                lr = r;
+                if (inst) lr = to_local(s.instances[inst], r);
+            }
+        }
+        float t;
+        if (leaf_hit<F>(p, lr, t_min, closest, t)) {
+            closest = t;
+            best = (int)i;
+        }
+    }
+}
+
+// ConstantMedium::hit (geo.rs:413-435).
+template <uint32_t F>
+MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, float t_min, float t_max, const DrawKey& key,
+                         float& t_out) {
+    uint32_t bfirst = __float_as_uint(p.a[0]), bcount = __float_as_uint(p.a[1]);
+    float t1 = MIRT_INF, t2 = MIRT_INF;
+    int b = -1;
+    boundary_scan<F>(s, bfirst, bcount, r, -MIRT_INF, t1, b);
+    if (b < 0) return false;
+    b = -1;
+    boundary_scan<F>(s, bfirst, bcount, r, t1 + 0.0001f, t2, b);
+    if (b < 0) return false;
+    t1 = fmaxf(fmaxf(t_min, t1), 0.f);
+    t2 = fminf(t_max, t2);
+    if (t1 >= t2) return false;
+    float distance_inside_boundary = t2 - t1;
+    uint32_t w0, w1, w2, w3;
+    philox4x32_10(key.pixel, key.sample, 0u, key.bounce, STREAM_MEDIUM + __float_as_uint(p.a[3]), key.seed, w0, w1, w2, w3);
+    float hit_distance = p.a[2] * logf(unit_f32(w0));
+    if (hit_distance > distance_inside_boundary) return false;
+    t_out = t1 + hit_distance;
+    return true;
+}
+
+// World-list scan with media allowed (scene.rs:290 world list through ray.rs:123-133).
+template <uint32_t F>
+MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const Ray& r, float t_min, const DrawKey& key,
+                        float& closest, int& best) {
+    uint32_t cur_inst = 0;
+    Ray lr = r;
+    for (uint32_t i = first; i < first + count; ++i) {
+        const DevPrim& p = s.prims[i];
+        float t;
+        bool h;
+        if ((F & F_MEDIUM) && (p.meta & PM_KIND_MASK) == PK_MEDIUM) {
+            h = medium_hit<F>(s, p, r, t_min, closest, key, t);
+        } else {
+            if (F & F_INSTANCE) {
+                uint32_t inst = p.instance;
+                if (inst != cur_inst) {
+                    cur_inst = inst;
+                    lr = r;
+                    if (inst) lr = to_local(s.instances[inst], r);
+                }
+            }
+            h = leaf_hit<F>(p, lr, t_min, closest, t);
+        }
+        if (h) {
+            closest = t;
+            best = (int)i;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// flattened BVH (the device form of aabb.rs BVHNode): 64-byte nodes holding both child boxes,
+// per-lane traversal stack in LDS
+// ---------------------------------------------------------------------------------------------
+constexpr int kBvhStackDepth = 32;
+
+MIRT_DEV bool slab(const float* lo, const float* hi, V3 o, V3 inv_d, float t_min, float t_max, float& t_near) {
+    float tx0 = (lo[0] - o.x) * inv_d.x, tx1 = (hi[0] - o.x) * inv_d.x;
+    float ty0 = (lo[1] - o.y) * inv_d.y, ty1 = (hi[1] - o.y) * inv_d.y;
+    float tz0 = (lo[2] - o.z) * inv_d.z, tz1 = (hi[2] - o.z) * inv_d.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
+    t_near = tn;
+    return tn <= tf * 1.0000004f;
+}
+
+template <uint32_t F>
+MIRT_DEV void bvh_leaf(const DevScene& s, const DevEntry& en, uint32_t slot, uint32_t n, const Ray& lr, float t_min,
+                       float& closest, int& best) {
+    for (uint32_t j = 0; j < n; ++j) {
+        uint32_t first = s.bvh_objects[slot + j];
+        for (uint32_t q = 0; q < en.prims_per_object; ++q) {
+            const DevPrim& p = s.prims[first + q];
+            float t;
+            if (leaf_hit<F>(p, lr, t_min, closest, t)) {
+                closest = t;
+                best = (int)(first + q);
+            }
+        }
+    }
+}
+
+// BVHNode::hit (aabb.rs:112-126) on the flattened tree. `stack` is this lane's column of an LDS
+// array laid out [level][lane] (stride = blockDim.x words), so pushes and pops are conflict-free.
+template <uint32_t F>
+MIRT_DEV void bvh_traverse(const DevScene& s, const DevEntry& en, const Ray& r, float t_min, float& closest, int& best,
+                           uint32_t* stack, uint32_t stride) {
+    Ray lr = r;
+    if ((F & F_INSTANCE) && en.instance) lr = to_local(s.instances[en.instance], r);
+    V3 inv_d = v3(1.f / lr.d.x, 1.f / lr.d.y, 1.f / lr.d.z);
+    uint32_t sp = 0;
+    uint32_t node = en.bvh_root;
+    for (;;) {
+        const DevBvhNode& nd = s.bvh_nodes[node];
+        float tn0, tn1;
+        bool h0 = slab(nd.lo0, nd.hi0, lr.o, inv_d, t_min, closest, tn0);
+        bool h1 = nd.c1 != 0xffffffffu && slab(nd.lo1, nd.hi1, lr.o, inv_d, t_min, closest, tn1);
+        uint32_t c0 = nd.c0, n0 = nd.n0, c1 = nd.c1, n1 = nd.n1;
+        // leaves are intersected immediately; interior children are visited near-first
+        if (h0 && n0) {
+            bvh_leaf<F>(s, en, c0, n0, lr, t_min, closest, best);
+            h0 = false;
+        }
+        if (h1 && n1) {
+            if (tn1 <= closest) bvh_leaf<F>(s, en, c1, n1, lr, t_min, closest, best);
+            h1 = false;
+        }
+        if (h0 && h1) {
+            bool first0 = tn0 <= tn1;
+            uint32_t far = first0 ? c1 : c0;
+            node = first0 ? c0 : c1;
+            if (sp < (uint32_t)kBvhStackDepth) stack[(sp++) * stride] = far;
+            continue;
+        }
+        if (h0) { node = c0; continue; }
+        if (h1) { node = c1; continue; }
+        if (sp == 0) break;
+        node = stack[(--sp) * stride];
+    }
+}
+
+// scene.world.hit(r, 0.001, inf) — renderer.rs:201.
+template <uint32_t F>
+MIRT_DEV void world_hit(const DevScene& s, const Ray& r, const DrawKey& key, uint32_t* stack, uint32_t stride, float& t_out,
+                        int& prim_out) {
+    float closest = MIRT_INF;
+    int best = -1;
+    for (uint32_t e = 0; e < s.n_entries; ++e) {
+        const DevEntry& en = s.entries[e];
+        if ((F & F_BVH) && en.kind == EK_BVH)
+            bvh_traverse<F>(s, en, r, 0.001f, closest, best, stack, stride);
+        else
+            list_scan<F>(s, en.first_prim, en.prim_count, r, 0.001f, key, closest, best);
+    }
+    t_out = closest;
+    prim_out = best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hit record reconstruction (HitRecord of ray.rs:50-81 as filled by geo.rs)
+// ---------------------------------------------------------------------------------------------
+struct HitInfo {
+    V3 p, n;
+    float u, v;
+    bool front;
+    uint32_t material;
+};
+
+template <uint32_t F>
+MIRT_DEV HitInfo finalize_hit(const DevScene& s, const Ray& r, float t, int prim) {
+    const DevPrim& p = s.prims[prim];
+    HitInfo h;
+    h.material = p.material;
+    h.u = 0.f;
+    h.v = 0.f;
+    uint32_t kind = p.meta & PM_KIND_MASK;
+    if ((F & F_MEDIUM) && kind == PK_MEDIUM) {
+        // geo.rs:427-431: default record — normal +y, front_face false, uv 0
+        h.p = ray_at(r, t);
+        h.n = v3(0.f, 1.f, 0.f);
+        h.front = false;
+        return h;
+    }
+    Ray lr = r;
+    uint32_t inst = (F & F_INSTANCE) ? p.instance : 0u;
+    if (inst) lr = to_local(s.instances[inst], r);
+    V3 pl = ray_at(lr, t);
+    V3 nl;
+    bool front;
+    if ((F & F_SPHERE) && (!(F & F_RECT) || kind == PK_SPHERE)) {
+        // geo.rs:108-111
+        V3 outward = (pl - sphere_center<F>(p, lr.time)) / p.a[3];
+        if (F & F_TEX_IMAGE) {
+            float theta = acosf(-outward.y);                    // geo.rs:71-75
+            float phi = atan2f(-outward.z, outward.x) + kPi;
+            h.u = phi / (2.f * kPi);
+            h.v = theta / kPi;
+        }
+        V3 on = normalize(outward);
+        front = dot(lr.d, on) < 0.f;
+        nl = front ? on : -on;
+    } else {
+        // geo.rs:205-211
+        uint32_t xi, yi, zi;
+        axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
+        if (F & F_TEX_IMAGE) {
+            h.u = (comp(pl, xi) - p.a[1]) / (p.a[2] - p.a[1]);
+            h.v = (comp(pl, yi) - p.a[3]) / (p.b[0] - p.a[3]);
+        }
+        front = comp(lr.d, zi) < 0.f;
+        float sgn = front ? 1.f : -1.f;
+        nl = v3(zi == 0 ? sgn : 0.f, zi == 1 ? sgn : 0.f, zi == 2 ? sgn : 0.f);
+    }
+    if (p.meta & PM_FLIP) front = !front;  // geo.rs:455-459: the flag flips, the normal does not
+    if (inst) {
+        const DevInstance& in = s.instances[inst];
+        h.p = rot_y(in, pl) + v3(in.ox, in.oy, in.oz);  // geo.rs:377-380 then geo.rs:309
+        h.n = rot_y(in, nl);
+    } else {
+        h.p = pl;
+        h.n = nl;
+    }
+    h.front = front;
+    return h;
+}
+
+// ---------------------------------------------------------------------------------------------
+// textures (texture.rs, perlin.rs)
+// ---------------------------------------------------------------------------------------------
+// perlin.rs:24-63
+MIRT_DEV float perlin_noise(const DevPerlin& pl, V3 p) {
+    float fl[3] = {floorf(p.x), floorf(p.y), floorf(p.z)};
+    int idx[3] = {(int)fl[0], (int)fl[1], (int)fl[2]};
+    float uvw[3];
+    const float pc[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float x = pc[a] - fl[a];
+        uvw[a] = x * x * (3.f - 2.f * x);
+    }
+    float accm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                int ind = pl.perm[0][(idx[0] + i) & 0xff] ^ pl.perm[1][(idx[1] + j) & 0xff] ^ pl.perm[2][(idx[2] + k) & 0xff];
+                V3 c = v3(pl.grad[ind][0], pl.grad[ind][1], pl.grad[ind][2]);
+                V3 weight = v3(uvw[0] - (float)i, uvw[1] - (float)j, uvw[2] - (float)k);
+                float prod = 1.f;
+                prod = prod * ((float)i * uvw[0] + (1.f - (float)i) * (1.f - uvw[0]));
+                prod = prod * ((float)j * uvw[1] + (1.f - (float)j) * (1.f - uvw[1]));
+                prod = prod * ((float)k * uvw[2] + (1.f - (float)k) * (1.f - uvw[2]));
+                accm += dot(c, weight) * prod;
+            }
+    return accm;
+}
+// perlin.rs:65-71
+MIRT_DEV float perlin_turb(const DevPerlin& pl, V3 p) {
+    float accum = 0.f, weight = 1.f;
+    V3 tp = p;
+    for (int i = 0; i < 7; ++i) {
+        accum = accum + weight * perlin_noise(pl, tp);
+        weight = 0.5f * weight;
+        tp = 2.f * tp;
+    }
+    return fabsf(accum);
+}
+
+template <uint32_t F>
+MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 p) {
+    const DevTexture& t = s.textures[tex];
+    uint32_t kind = t.kind;
+    if ((F & F_TEX_CHECKER) && kind == TK_CHECKER) {
+        // texture.rs:42-46
+        float sines = 1.0f;
+        sines = sines * sinf(10.f * p.x);
+        sines = sines * sinf(10.f * p.y);
+        sines = sines * sinf(10.f * p.z);
+        return sines < 0.f ? v3(t.c1) : v3(t.c0);
+    }
+    if ((F & F_TEX_NOISE) && kind == TK_NOISE) {
+        // texture.rs:64-68
+        float g = 0.5f * (1.f + sinf(t.c1[3] * p.z + 10.f * perlin_turb(s.perlins[t.perlin], p)));
+        return v3(g, g, g);
+    }
+    if ((F & F_TEX_IMAGE) && kind == TK_IMAGE) {
+        // texture.rs:91-102
+        const DevImage& im = s.images[t.image];
+        if (im.width == 0) return v3(0.f, 1.f, 1.f);
+        float cu = fminf(fmaxf(u, 0.f), 1.f), cv = fminf(fmaxf(v, 0.f), 1.f);
+        uint32_t x = min((uint32_t)(cu * (float)im.width), im.width - 1);
+        uint32_t y = min((uint32_t)(cv * (float)im.height), im.height - 1);
+        uchar4 px = reinterpret_cast<const uchar4*>(im.rgba)[(size_t)y * im.width + x];
+        const float sc = 1.f / 255.f;
+        return v3((float)px.x * sc, (float)px.y * sc, (float)px.z * sc);
+    }
+    return v3(t.c0);  // texture.rs:21-25
+}
+
+// ---------------------------------------------------------------------------------------------
+// light list: HittableList::{pdf_val, random} (ray.rs:149-154) over scene.lights
+// ---------------------------------------------------------------------------------------------
+// geo.rs:223-233 (rect) and geo.rs:136-143 (sphere). Instances are not applied and FlipFace is
+// transparent, as in geo.rs:324-329 and geo.rs:465-470.
+template <uint32_t F>
+MIRT_DEV float light_pdf_one(const DevPrim& p, V3 origin, V3 v) {
+    uint32_t kind = p.meta & PM_KIND_MASK;
+    if ((F & F_RECT) && kind == PK_RECT) {
+        Ray pr{origin, v, 0.2f};
+        float t;
+        if (!rect_hit(p, pr, 0.001f, MIRT_INF, t)) return 0.f;
+        uint32_t xi, yi, zi;
+        axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
+        float area = fabsf((p.a[2] - p.a[1]) * (p.b[0] - p.a[3]));
+        float dis_squared = t * t * norm_squared(v);
+        float cosine = fabsf(comp(v, zi));
+        return dis_squared / (cosine * area);
+    }
+    if ((F & F_SPHERE) && kind == PK_SPHERE) {
+        Ray pr{origin, v, 0.f};
+        float t;
+        if (!sphere_hit_c(sphere_center<F>(p, 0.f), p.a[3], pr, 0.001f, MIRT_INF, t)) return 0.f;
+        V3 c0 = v3(p.a[0], p.a[1], p.a[2]);
+        float cos_theta_max = sqrtf(1.f - p.a[3] * p.a[3] / norm_squared(c0 - origin));
+        float solid_angle = 2.f * kPi * (1.f - cos_theta_max);
+        return 1.f / solid_angle;
+    }
+    return 0.f;
+}
+
+template <uint32_t F>
+MIRT_DEV float lights_pdf(const DevScene& s, V3 origin, V3 v) {
+    float sum = 0.f;
+    for (uint32_t i = 0; i < s.n_lights; ++i) sum += light_pdf_one<F>(s.prims[s.lights[i]], origin, v);
+    return sum / (float)s.n_lights;
+}
+
+// geo.rs:234-242 (rect) and geo.rs:144-149 with geo.rs:77-85 (sphere): two draws each.
+template <uint32_t F>
+MIRT_DEV V3 light_random_one(const DevPrim& p, V3 origin, float xi1, float xi2) {
+    uint32_t kind = p.meta & PM_KIND_MASK;
+    if ((F & F_RECT) && kind == PK_RECT) {
+        uint32_t xi, yi, zi;
+        axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
+        float a = p.a[1] + (p.a[2] - p.a[1]) * xi1;
+        float b = p.a[3] + (p.b[0] - p.a[3]) * xi2;
+        float k = p.b[1];
+        V3 pt = v3(xi == 0 ? a : (yi == 0 ? b : k), xi == 1 ? a : (yi == 1 ? b : k), xi == 2 ? a : (yi == 2 ? b : k));
+        return normalize(pt - origin);
+    }
+    if ((F & F_SPHERE) && kind == PK_SPHERE) {
+        V3 c0 = v3(p.a[0], p.a[1], p.a[2]);
+        V3 direction = c0 - origin;
+        float d = norm_squared(direction);
+        Onb uvw = onb_from_w(normalize(direction));
+        float r1 = xi1, r2 = xi2;
+        float z = 1.f + r2 * (sqrtf(1.f - p.a[3] * p.a[3] / d) - 1.f);
+        float phi = 2.f * kPi * r1;
+        float sn, cs;
+        sincosf(phi, &sn, &cs);
+        float x = cs * sqrtf(1.f - z * z);
+        float y = sn * sqrtf(1.f - z * z);
+        return onb_local(uvw, v3(x, y, z));
+    }
+    return v3(1.f, 0.f, 0.f);  // ray.rs:41-43
+}
+
+// ---------------------------------------------------------------------------------------------
+// one level of ray_color (renderer.rs:197-237) after world.hit found `prim` at `t`
+// ---------------------------------------------------------------------------------------------
+enum ShadeResult { SHADE_CONTINUE = 0, SHADE_TERMINATE = 1 };
+
+// On SHADE_CONTINUE: `ray` is the scattered ray and `thr` has been multiplied by
+// attenuation / divisor. On SHADE_TERMINATE: `radiance` is what this level returns to its caller
+// (emission, or 0 when the ray is absorbed), not yet multiplied by thr.
+template <uint32_t F>
+MIRT_DEV ShadeResult shade(const DevScene& s, Ray& ray, float t, int prim, const DrawKey& key, V3& thr, V3& radiance) {
+    HitInfo h = finalize_hit<F>(s, ray, t, prim);
+    const DevMaterial& m = s.materials[h.material];
+    uint32_t mk = m.kind;
+    radiance = v3(0.f, 0.f, 0.f);
+    Rng g;
+    g.init(key.pixel, key.sample, key.bounce, STREAM_SCATTER, key.seed);
+
+    if ((F & F_MAT_LIGHT) && mk == MK_DIFFUSE_LIGHT) {
+        // material.rs:167-175: never scatters, emits toward front_face only
+        if (h.front) radiance = texture_value<F>(s, m.texture, h.u, h.v, h.p);
+        return SHADE_TERMINATE;
+    }
+    if ((F & F_MAT_METAL) && mk == MK_METAL) {
+        // material.rs:86-100
+        V3 reflected = ray.d - (2.f * dot(h.n, ray.d)) * h.n;
+        V3 sd = reflected + m.param * rand_in_unit_sphere(g);
+        if (!(dot(h.n, sd) > 0.f)) return SHADE_TERMINATE;
+        ray.o = h.p;
+        ray.d = normalize(sd);
+        thr = cmul(thr, v3(m.albedo));
+        return SHADE_CONTINUE;
+    }
+    if ((F & F_MAT_DIELECTRIC) && mk == MK_DIELECTRIC) {
+        // material.rs:129-151
+        float ratio = h.front ? 1.f / m.param : m.param;
+        float cos_theta = fminf(-dot(ray.d, h.n), 1.f);
+        float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+        bool reflect = ratio * sin_theta > 1.f;
+        if (!reflect) {
+            float r0 = (1.f - ratio) / (1.f + ratio);
+            r0 = r0 * r0;
+            float x = 1.f - cos_theta;
+            float x2 = x * x;
+            float refl = r0 + (1.f - r0) * (x2 * x2 * x);  // material.rs:121-125
+            reflect = refl > g.next();
+        }
+        V3 dir;
+        if (reflect) {
+            dir = ray.d - (2.f * dot(h.n, ray.d)) * h.n;  // material.rs:75-77
+        } else {
+            // material.rs:114-119
+            float ct = fminf(-dot(ray.d, h.n), 1.f);
+            V3 perp = ratio * (ray.d + ct * h.n);
+            V3 par = (-sqrtf(fabsf(1.f - norm_squared(perp)))) * h.n;
+            dir = normalize(perp + par);
+        }
+        ray.o = h.p;
+        ray.d = dir;
+        return SHADE_CONTINUE;  // attenuation 1, divisor 1
+    }
+    if ((F & F_MAT_ISOTROPIC) && mk == MK_ISOTROPIC) {
+        // material.rs:194-199
+        V3 dir = normalize(rand_in_unit_sphere(g));
+        V3 att = texture_value<F>(s, m.texture, h.u, h.v, h.p);
+        ray.o = h.p;
+        ray.d = dir;
+        thr = cmul(thr, att);
+        return SHADE_CONTINUE;
+    }
+    // Lambertian — material.rs:51-61 with the mixture of renderer.rs:207-221
+    V3 att = texture_value<F>(s, m.texture, h.u, h.v, h.p);
+    Onb uvw = onb_from_w(h.n);
+    V3 dir;
+    float pdf_val;
+    if (s.n_lights == 0) {
+        float a = g.next(), b = g.next();
+        dir = onb_local(uvw, random_cosine_direction(a, b));       // pdf.rs:30-32
+        float c = dot(dir, uvw.w);
+        pdf_val = c <= 0.f ? 0.0001f : c / kPi;                     // pdf.rs:25-28
+    } else {
+        float sel = g.next();
+        float a = g.next(), b = g.next();
+        if (sel < 0.5f) {                                           // pdf.rs:77-83
+            dir = onb_local(uvw, random_cosine_direction(a, b));
+        } else {
+            float c = g.next();
+            // ray.rs:152-154: member floor(n * xi)
+            uint32_t li = (uint32_t)(0.f + ((float)s.n_lights - 0.f) * a);
+            li = min(li, s.n_lights - 1);
+            dir = light_random_one<F>(s.prims[s.lights[li]], h.p, b, c);
+        }
+        float c = dot(dir, uvw.w);
+        float p0 = c <= 0.f ? 0.0001f : c / kPi;
+        float p1 = lights_pdf<F>(s, h.p, dir);
+        pdf_val = 0.5f * p0 + 0.5f * p1;                            // pdf.rs:73-75
+    }
+    float cosine = fmaxf(dot(dir, h.n), 0.0001f);                   // renderer.rs:219
+    float divisor = pdf_val / cosine * kPi * 2.f;                   // renderer.rs:221
+    ray.o = h.p;
+    ray.d = dir;
+    thr = cmul(thr, att) / divisor;                                 // renderer.rs:227
+    return SHADE_CONTINUE;
+}
+
+// cal_norm_coords (renderer.rs:174-184) + Camera::get_ray (camera.rs:86-94)
+MIRT_DEV Ray camera_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t width, uint32_t height, bool jitter, Rng& g) {
+    float xo = 0.f, yo = 0.f;
+    if (jitter) {
+        xo = g.next();
+        yo = g.next();
+    }
+    float s = ((float)x + xo) / (float)(width - 1);
+    float t = ((float)y + yo) / (float)(height - 1);
+    V3 rd = cam.lens_radius * rand_in_unit_disk(g);
+    V3 offset = v3(cam.u) * rd.x + v3(cam.v) * rd.y;
+    Ray r;
+    r.o = v3(cam.origin) + offset;
+    r.d = normalize((((v3(cam.llc) + s * v3(cam.horizontal)) + t * v3(cam.vertical)) - v3(cam.origin)) - offset);
+    r.time = g.range(cam.time0, cam.time1);
+    return r;
+}
+
+// renderer.rs:107 — NaN -> 0, +-inf -> 1.
+MIRT_DEV float sanitize(float c) { return isnan(c) ? 0.f : (isinf(c) ? 1.f : c); }
+
+}  // namespace mirt

@@ -1,0 +1,118 @@
+// Device-resident scene layout. Built once by the upload code from the mirt_scene_desc arrays and
+// passed to every kernel by value (it lands in SGPRs / the kernarg segment). Everything a ray
+// touches per primitive is a multiple of 16 bytes so that one primitive is three dwordx4 loads —
+// scalar loads when the index is wave-uniform (list scans), vector loads in BVH leaves.
+#pragma once
+#include <stdint.h>
+
+namespace mirt {
+
+// meta word of DevPrim
+enum : uint32_t {
+    PK_SPHERE = 0, PK_RECT = 1, PK_MEDIUM = 2,
+    PM_KIND_MASK = 3u,
+    PM_AXIS_SHIFT = 2, PM_AXIS_MASK = 3u << 2,
+    PM_FLIP = 1u << 4,
+    PM_MOVING = 1u << 5,
+};
+
+struct __attribute__((aligned(16))) DevPrim {
+    // sphere: a = (center0.xyz, radius)        b = (center1.xyz, time0)     c0 = time1
+    // rect:   a = (k, lo0, hi0, lo1)           b = (hi1, k_mid, 0, 0)
+    // medium: a = (bits boundary_first, bits boundary_count, neg_inv_density, bits medium_index)
+    float a[4];
+    float b[4];
+    float c0;
+    uint32_t material;
+    uint32_t instance;
+    uint32_t meta;
+};
+static_assert(sizeof(DevPrim) == 48, "DevPrim is three 16-byte quads");
+
+struct __attribute__((aligned(16))) DevInstance {
+    float sin_t, cos_t, ox, oy;
+    float oz, pad0, pad1, pad2;
+};
+
+struct __attribute__((aligned(16))) DevMaterial {
+    uint32_t kind, texture;
+    float param, pad;
+    float albedo[4];
+};
+
+struct __attribute__((aligned(16))) DevTexture {
+    uint32_t kind, perlin, image, pad;
+    float c0[4];  // solid colour / checker even
+    float c1[4];  // checker odd; c1[3] = noise scale
+};
+
+struct DevImage {
+    uint32_t width, height;
+    const uint8_t* rgba;  // device pointer
+};
+
+struct __attribute__((aligned(16))) DevPerlin {
+    float grad[256][4];
+    uint8_t perm[3][256];
+};
+
+enum : uint32_t { EK_LIST = 0, EK_BVH = 1 };
+struct __attribute__((aligned(16))) DevEntry {
+    uint32_t kind;
+    uint32_t first_prim;
+    uint32_t prim_count;
+    uint32_t prims_per_object;
+    uint32_t instance;
+    uint32_t bvh_root;   // index of the root node in bvh_nodes
+    uint32_t pad0, pad1;
+};
+
+// 64-byte node holding the boxes of both children, so one interior step is one 64-byte fetch.
+// Child i: n_i == 0 -> interior node index c_i; n_i > 0 -> leaf of n_i objects starting at slot c_i
+// of bvh_objects (each slot is the index of the object's first prim). c1 == 0xffffffff marks a
+// missing second child (single-leaf tree).
+struct __attribute__((aligned(16))) DevBvhNode {
+    float lo0[3];
+    uint32_t c0;
+    float hi0[3];
+    uint32_t n0;
+    float lo1[3];
+    uint32_t c1;
+    float hi1[3];
+    uint32_t n1;
+};
+static_assert(sizeof(DevBvhNode) == 64, "DevBvhNode is four 16-byte quads");
+
+enum : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4 };
+enum : uint32_t { TK_SOLID = 0, TK_CHECKER = 1, TK_NOISE = 2, TK_IMAGE = 3 };
+
+struct DevCamera {
+    float origin[3], llc[3], horizontal[3], vertical[3], u[3], v[3];
+    float lens_radius, time0, time1;
+};
+
+// feature bits: which code the scene needs (selects the kernel specialisation)
+enum : uint32_t {
+    F_SPHERE = 1u << 0, F_RECT = 1u << 1, F_MEDIUM = 1u << 2, F_INSTANCE = 1u << 3, F_MOVING = 1u << 4,
+    F_BVH = 1u << 5, F_TEX_CHECKER = 1u << 6, F_TEX_NOISE = 1u << 7, F_TEX_IMAGE = 1u << 8,
+    F_MAT_METAL = 1u << 9, F_MAT_DIELECTRIC = 1u << 10, F_MAT_ISOTROPIC = 1u << 11, F_MAT_LIGHT = 1u << 12,
+    F_ALL = 0x1fffu,
+};
+
+struct DevScene {
+    const DevPrim* prims;
+    const DevEntry* entries;
+    const uint32_t* lights;
+    const DevMaterial* materials;
+    const DevTexture* textures;
+    const DevImage* images;
+    const DevPerlin* perlins;
+    const DevInstance* instances;
+    const DevBvhNode* bvh_nodes;
+    const uint32_t* bvh_objects;
+    uint32_t n_prims, n_entries, n_lights, n_media;
+    uint32_t features;
+    float background[3];
+};
+
+}  // namespace mirt

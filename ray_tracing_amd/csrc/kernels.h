@@ -1,0 +1,36 @@
+// Launch interface between the C-ABI layer (mirt_api.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_types.h"
+
+namespace mirt {
+
+struct RenderArgs {
+    DevScene scene;
+    DevCamera cam;
+    uint32_t width, height;
+    uint32_t spp_begin, spp_count;
+    uint32_t max_depth, seed, jitter;
+    float4* accum;                      // width*height, pixel y*width + x, y = 0 at the bottom
+    unsigned long long* segment_counter;
+};
+
+struct RayBatchArgs {
+    DevScene scene;
+    const float* rays;  // n x 7: origin, direction, time
+    uint32_t n;
+    uint32_t sample, max_depth, seed;
+    int32_t* prim_id;   // first_hit
+    float* t;           // first_hit
+    float* aov;         // first_hit, optional, n x 12
+    float* color;       // ray_color, n x 3
+};
+
+// One thread per pixel walks all samples of the call: camera ray, then one ray segment per loop
+// iteration (trace + shade) with the path state in registers.
+hipError_t launch_render_fused(const RenderArgs& a, hipStream_t stream);
+hipError_t launch_first_hit(const RayBatchArgs& a, hipStream_t stream);
+hipError_t launch_ray_color(const RayBatchArgs& a, hipStream_t stream);
+hipError_t launch_resolve_rgba8(const float4* accum, uint8_t* frame, uint32_t width, uint32_t height, hipStream_t stream);
+
+}  // namespace mirt

@@ -1,0 +1,237 @@
+// gfx950 kernels of the path-tracing backend.
+//
+//   render_fused_kernel  the per-pixel sample loop of Renderer::draw (renderer.rs:97-110): one
+//                        lane owns one pixel and walks its samples; each loop iteration is one ray
+//                        segment of ray_color (renderer.rs:197-237) — trace, shade, scatter — with
+//                        ray, throughput and RNG position in registers. A lane that finishes a
+//                        path starts its next sample in the same iteration, so the 64 lanes of a
+//                        wave stay busy although path lengths differ from 1 to max_depth.
+//   first_hit_kernel     world.hit(ray, 0.001, inf) for explicit rays (deterministic check).
+//   ray_color_kernel     one un-sanitised radiance sample per explicit ray.
+//   resolve_kernel       mean, clamp, sqrt, *256 -> RGBA8 with the row flip (renderer.rs:97,109-116).
+#include "kernels.h"
+#include "dev_core.h"
+
+namespace mirt {
+
+constexpr int kBlock = 256;
+
+// Pixel owned by a thread: a 256-thread block covers 32x8 pixels, each wave an 8x8 tile, so the
+// lanes of a wave trace neighbouring paths.
+__device__ __forceinline__ void thread_pixel(uint32_t width, uint32_t& x, uint32_t& y) {
+    uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t tiles_x = (width + 31u) / 32u;
+    uint32_t bx = blockIdx.x % tiles_x, by = blockIdx.x / tiles_x;
+    x = bx * 32u + wave * 8u + (lane & 7u);
+    y = by * 8u + (lane >> 3);
+}
+
+template <uint32_t F>
+__global__ __launch_bounds__(kBlock) void render_fused_kernel(RenderArgs a) {
+    __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
+    uint32_t* stack = bvh_stack + threadIdx.x;
+
+    uint32_t x, y;
+    thread_pixel(a.width, x, y);
+    const bool valid = x < a.width && y < a.height;
+    const uint32_t pixel = y * a.width + x;
+
+    V3 acc = v3(0.f, 0.f, 0.f);
+    uint32_t segments = 0;
+    if (valid && a.max_depth > 0) {
+        uint32_t sample = a.spp_begin;
+        const uint32_t sample_end = a.spp_begin + a.spp_count;
+        uint32_t depth_left = 0, bounce = 0;
+        Ray ray;
+        V3 thr = v3(1.f, 1.f, 1.f);
+        while (sample < sample_end) {
+            if (depth_left == 0) {
+                Rng g;
+                g.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
+                ray = camera_ray(a.cam, x, y, a.width, a.height, a.jitter != 0, g);
+                thr = v3(1.f, 1.f, 1.f);
+                depth_left = a.max_depth;
+                bounce = 0;
+            }
+            DrawKey key{pixel, sample, bounce, a.seed};
+            float t;
+            int prim;
+            world_hit<F>(a.scene, ray, key, stack, kBlock, t, prim);
+            ++segments;
+            bool done;
+            V3 e;
+            if (prim < 0) {
+                e = cmul(thr, v3(a.scene.background));  // renderer.rs:233-235
+                done = true;
+            } else {
+                V3 rad;
+                ShadeResult sr = shade<F>(a.scene, ray, t, prim, key, thr, rad);
+                if (sr == SHADE_TERMINATE) {
+                    e = cmul(thr, rad);
+                    done = true;
+                } else {
+                    --depth_left;
+                    ++bounce;
+                    done = depth_left == 0;  // renderer.rs:198-200: the next level returns 0
+                    e = v3(0.f, 0.f, 0.f);
+                }
+            }
+            if (done) {
+                acc = acc + v3(sanitize(e.x), sanitize(e.y), sanitize(e.z));  // renderer.rs:107-109
+                ++sample;
+                depth_left = 0;
+            }
+        }
+    }
+    if (valid) {
+        float4 v = a.accum[pixel];
+        v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += (float)a.spp_count;
+        a.accum[pixel] = v;
+    }
+    // one atomic per wave for the segment count
+    for (int off = 32; off > 0; off >>= 1) segments += __shfl_down(segments, off);
+    if ((threadIdx.x & 63u) == 0 && a.segment_counter) atomicAdd(a.segment_counter, (unsigned long long)segments);
+}
+
+template <uint32_t F>
+__global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
+    __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
+    uint32_t* stack = bvh_stack + threadIdx.x;
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const float* q = a.rays + (size_t)i * 7;
+    Ray ray{v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
+    DrawKey key{i, 0u, 0u, a.seed};
+    float t;
+    int prim;
+    world_hit<F>(a.scene, ray, key, stack, kBlock, t, prim);
+    a.prim_id[i] = prim;
+    a.t[i] = t;
+    if (a.aov) {
+        float* o = a.aov + (size_t)i * 12;
+        for (int k = 0; k < 12; ++k) o[k] = 0.f;
+        if (prim >= 0) {
+            HitInfo h = finalize_hit<F>(a.scene, ray, t, prim);
+            const DevMaterial& m = a.scene.materials[h.material];
+            V3 c = v3(1.f, 1.f, 1.f);
+            if (m.kind == MK_METAL) c = v3(m.albedo);
+            else if (m.kind != MK_DIELECTRIC) c = texture_value<F>(a.scene, m.texture, h.u, h.v, h.p);
+            o[0] = h.p.x; o[1] = h.p.y; o[2] = h.p.z;
+            o[3] = h.n.x; o[4] = h.n.y; o[5] = h.n.z;
+            o[6] = h.front ? 1.f : 0.f; o[7] = h.u; o[8] = h.v;
+            o[9] = c.x; o[10] = c.y; o[11] = c.z;
+        }
+    }
+}
+
+template <uint32_t F>
+__global__ __launch_bounds__(kBlock) void ray_color_kernel(RayBatchArgs a) {
+    __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
+    uint32_t* stack = bvh_stack + threadIdx.x;
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= a.n) return;
+    const float* q = a.rays + (size_t)i * 7;
+    Ray ray{v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
+    V3 thr = v3(1.f, 1.f, 1.f);
+    V3 e = v3(0.f, 0.f, 0.f);
+    for (uint32_t bounce = 0; bounce < a.max_depth; ++bounce) {
+        DrawKey key{i, a.sample, bounce, a.seed};
+        float t;
+        int prim;
+        world_hit<F>(a.scene, ray, key, stack, kBlock, t, prim);
+        if (prim < 0) {
+            e = cmul(thr, v3(a.scene.background));
+            break;
+        }
+        V3 rad;
+        if (shade<F>(a.scene, ray, t, prim, key, thr, rad) == SHADE_TERMINATE) {
+            e = cmul(thr, rad);
+            break;
+        }
+    }
+    a.color[(size_t)i * 3 + 0] = e.x;
+    a.color[(size_t)i * 3 + 1] = e.y;
+    a.color[(size_t)i * 3 + 2] = e.z;
+}
+
+// renderer.rs:135-137
+__device__ __forceinline__ uint8_t float_to_rgb(float num) {
+    float c = fminf(fmaxf(num, 0.f), 0.999f);
+    return (uint8_t)(sqrtf(c) * 256.f);
+}
+
+__global__ __launch_bounds__(kBlock) void resolve_kernel(const float4* accum, uchar4* frame, uint32_t width, uint32_t height) {
+    uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= width * height) return;
+    uint32_t fy = i / width, x = i - fy * width;
+    uint32_t y = height - 1u - fy;  // renderer.rs:97: renderer row 0 is the LAST frame row
+    float4 s = accum[y * width + x];
+    float n = s.w;
+    uchar4 px;
+    px.x = float_to_rgb(s.x / n);
+    px.y = float_to_rgb(s.y / n);
+    px.z = float_to_rgb(s.z / n);
+    px.w = 0xff;
+    frame[i] = px;
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernel specialisations: the smallest feature mask that covers the scene is launched
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kVariantBox = F_SPHERE | F_RECT | F_INSTANCE | F_MAT_DIELECTRIC | F_MAT_LIGHT | F_MAT_METAL;
+constexpr uint32_t kVariantSmoke = kVariantBox | F_MEDIUM | F_MAT_ISOTROPIC;
+constexpr uint32_t kVariantSpheres = F_SPHERE | F_MOVING | F_BVH | F_TEX_CHECKER | F_MAT_METAL | F_MAT_DIELECTRIC | F_MAT_LIGHT | F_RECT;
+constexpr uint32_t kVariantAll = F_ALL;
+
+template <template <uint32_t> class Launcher, class Args>
+static hipError_t dispatch(uint32_t features, const Args& a, hipStream_t stream) {
+    if ((features & ~kVariantBox) == 0) return Launcher<kVariantBox>::run(a, stream);
+    if ((features & ~kVariantSmoke) == 0) return Launcher<kVariantSmoke>::run(a, stream);
+    if ((features & ~kVariantSpheres) == 0) return Launcher<kVariantSpheres>::run(a, stream);
+    return Launcher<kVariantAll>::run(a, stream);
+}
+
+template <uint32_t F>
+struct RenderLauncher {
+    static hipError_t run(const RenderArgs& a, hipStream_t stream) {
+        uint32_t tiles = ((a.width + 31u) / 32u) * ((a.height + 7u) / 8u);
+        hipLaunchKernelGGL(render_fused_kernel<F>, dim3(tiles), dim3(kBlock), 0, stream, a);
+        return hipGetLastError();
+    }
+};
+template <uint32_t F>
+struct FirstHitLauncher {
+    static hipError_t run(const RayBatchArgs& a, hipStream_t stream) {
+        hipLaunchKernelGGL(first_hit_kernel<F>, dim3((a.n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
+        return hipGetLastError();
+    }
+};
+template <uint32_t F>
+struct RayColorLauncher {
+    static hipError_t run(const RayBatchArgs& a, hipStream_t stream) {
+        hipLaunchKernelGGL(ray_color_kernel<F>, dim3((a.n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
+        return hipGetLastError();
+    }
+};
+
+hipError_t launch_render_fused(const RenderArgs& a, hipStream_t stream) {
+    if (a.width == 0 || a.height == 0 || a.spp_count == 0) return hipSuccess;
+    return dispatch<RenderLauncher>(a.scene.features, a, stream);
+}
+hipError_t launch_first_hit(const RayBatchArgs& a, hipStream_t stream) {
+    if (a.n == 0) return hipSuccess;
+    return dispatch<FirstHitLauncher>(a.scene.features, a, stream);
+}
+hipError_t launch_ray_color(const RayBatchArgs& a, hipStream_t stream) {
+    if (a.n == 0) return hipSuccess;
+    return dispatch<RayColorLauncher>(a.scene.features, a, stream);
+}
+hipError_t launch_resolve_rgba8(const float4* accum, uint8_t* frame, uint32_t width, uint32_t height, hipStream_t stream) {
+    uint32_t n = width * height;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(resolve_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, accum,
+                       reinterpret_cast<uchar4*>(frame), width, height);
+    return hipGetLastError();
+}
+
+}  // namespace mirt

@@ -1,0 +1,629 @@
+// C-ABI layer of libmirt.so (see include/mirt.h): context, scene flattening + upload, BVH build,
+// frame / accumulation management and the launches. No exception crosses the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mirt.h"
+#include "bvh_build.h"
+#include "dev_types.h"
+#include "kernels.h"
+
+using namespace mirt;
+
+struct mirt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    std::vector<void*> scene_allocs;
+    DevScene scene{};
+    DevCamera cam{};
+    bool has_scene = false, has_camera = false;
+    float4* accum = nullptr;
+    float4* accum_owned = nullptr;
+    size_t accum_owned_pixels = 0;
+    uint32_t width = 0, height = 0;
+    uint8_t* frame_dev = nullptr;
+    size_t frame_dev_bytes = 0;
+    unsigned long long* seg_counter = nullptr;
+    mirt_stats stats{};
+};
+
+namespace {
+thread_local std::string g_create_err;
+
+int fail(mirt_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_err = msg;
+    return code;
+}
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail((ctx), MIRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+void free_scene(mirt_ctx* c) {
+    for (void* p : c->scene_allocs) (void)hipFree(p);
+    c->scene_allocs.clear();
+    c->scene = DevScene{};
+    c->has_scene = false;
+}
+
+template <class T>
+int upload(mirt_ctx* c, const std::vector<T>& v, const T** out) {
+    *out = nullptr;
+    if (v.empty()) {
+        // keep every table pointer valid so a kernel never dereferences null
+        void* p = nullptr;
+        HIP_TRY(c, hipMalloc(&p, 64));
+        HIP_TRY(c, hipMemset(p, 0, 64));
+        c->scene_allocs.push_back(p);
+        *out = static_cast<const T*>(p);
+        return MIRT_OK;
+    }
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, v.size() * sizeof(T)));
+    c->scene_allocs.push_back(p);
+    HIP_TRY(c, hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(p);
+    return MIRT_OK;
+}
+
+void rot_y_host(const mirt_instance& in, const float p[3], float out[3]) {
+    out[0] = in.cos_theta * p[0] + in.sin_theta * p[2];
+    out[1] = p[1];
+    out[2] = -in.sin_theta * p[0] + in.cos_theta * p[2];
+}
+
+// Bounding box of one leaf primitive over shutter times [0,1] (geo.rs:116-130, 218-221), in the
+// coordinate frame of its entry (a primitive's own instance applied, geo.rs:340-368, 317-323).
+void prim_bounds(const mirt_prim& p, const mirt_instance* instances, float lo[3], float hi[3]) {
+    float l[3], h[3];
+    if (p.kind == MIRT_PRIM_SPHERE) {
+        for (int a = 0; a < 3; ++a) {
+            float c0 = p.center0[a], c1 = c0;
+            if (p.flags & MIRT_PRIM_MOVING) {
+                float d = p.center1[a] - p.center0[a];
+                c0 = p.center0[a] + (0.f - p.time0) / (p.time1 - p.time0) * d;
+                c1 = p.center0[a] + (1.f - p.time0) / (p.time1 - p.time0) * d;
+            }
+            float r = std::fabs(p.radius);
+            l[a] = std::min(c0, c1) - r;
+            h[a] = std::max(c0, c1) + r;
+        }
+    } else {
+        int xi = p.axis == MIRT_AXIS_YZ ? 1 : 0;
+        int yi = p.axis == MIRT_AXIS_XY ? 1 : 2;
+        int zi = p.axis == MIRT_AXIS_XY ? 2 : (p.axis == MIRT_AXIS_XZ ? 1 : 0);
+        l[xi] = p.lo[0]; h[xi] = p.hi[0];
+        l[yi] = p.lo[1]; h[yi] = p.hi[1];
+        l[zi] = p.k - 0.0001f; h[zi] = p.k + 0.0001f;
+    }
+    if (p.instance) {
+        const mirt_instance& in = instances[p.instance];
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int i = 0; i < 8; ++i) {
+            float c[3] = {(i & 1) ? h[0] : l[0], (i & 2) ? h[1] : l[1], (i & 4) ? h[2] : l[2]}, q[3];
+            rot_y_host(in, c, q);
+            for (int a = 0; a < 3; ++a) {
+                q[a] += in.offset[a];
+                mn[a] = std::min(mn[a], q[a]);
+                mx[a] = std::max(mx[a], q[a]);
+            }
+        }
+        for (int a = 0; a < 3; ++a) { l[a] = mn[a]; h[a] = mx[a]; }
+    }
+    for (int a = 0; a < 3; ++a) { lo[a] = l[a]; hi[a] = h[a]; }
+}
+}  // namespace
+
+extern "C" {
+
+const char* mirt_last_error(const mirt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int mirt_create(int device, mirt_ctx** out) {
+    if (!out) return fail(nullptr, MIRT_ERR_INVALID, "mirt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(nullptr, MIRT_ERR_NO_DEVICE, "mirt_create: no HIP device available");
+    if (device < 0 || device >= n) return fail(nullptr, MIRT_ERR_INVALID, "mirt_create: device index out of range");
+    mirt_ctx* c = new (std::nothrow) mirt_ctx();
+    if (!c) return fail(nullptr, MIRT_ERR_INVALID, "mirt_create: out of host memory");
+    c->device = device;
+    auto bail = [&](const char* what, hipError_t err) {
+        g_create_err = std::string(what) + ": " + hipGetErrorString(err);
+        mirt_destroy(c);
+        return MIRT_ERR_HIP;
+    };
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->seg_counter, 0, sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    *out = c;
+    return MIRT_OK;
+}
+
+void mirt_destroy(mirt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_scene(c);
+    if (c->accum_owned) (void)hipFree(c->accum_owned);
+    if (c->frame_dev) (void)hipFree(c->frame_dev);
+    if (c->seg_counter) (void)hipFree(c->seg_counter);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (!d) return fail(c, MIRT_ERR_INVALID, "mirt_scene_upload: desc is NULL");
+    auto bad = [&](const std::string& m) { return fail(c, MIRT_ERR_INVALID, "mirt_scene_upload: " + m); };
+    if (d->n_prims && !d->prims) return bad("prims is NULL");
+    if (d->n_world && !d->world) return bad("world is NULL");
+    if (d->n_lights && !d->lights) return bad("lights is NULL");
+    if (d->n_materials == 0 || !d->materials) return bad("no materials");
+    if (d->n_textures && !d->textures) return bad("textures is NULL");
+    if (d->n_perlins && !d->perlins) return bad("perlins is NULL");
+    if (d->n_images && !d->images) return bad("images is NULL");
+    if (d->n_instances && !d->instances) return bad("instances is NULL");
+
+    uint32_t features = 0;
+    // ---- validate + convert primitives
+    std::vector<DevPrim> prims(d->n_prims);
+    uint32_t n_media = 0;
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const mirt_prim& p = d->prims[i];
+        DevPrim q{};
+        if (p.material >= d->n_materials) return bad("prim " + std::to_string(i) + ": material index out of range");
+        if (p.instance && p.instance >= d->n_instances) return bad("prim " + std::to_string(i) + ": instance index out of range");
+        q.material = p.material;
+        q.instance = p.instance;
+        if (p.instance) features |= F_INSTANCE;
+        if (p.kind == MIRT_PRIM_SPHERE) {
+            features |= F_SPHERE;
+            q.meta = PK_SPHERE;
+            for (int a = 0; a < 3; ++a) { q.a[a] = p.center0[a]; q.b[a] = p.center1[a]; }
+            q.a[3] = p.radius;
+            q.b[3] = p.time0;
+            q.c0 = p.time1;
+            if (p.flags & MIRT_PRIM_MOVING) {
+                if (p.time0 == p.time1) return bad("prim " + std::to_string(i) + ": moving sphere with time0 == time1");
+                q.meta |= PM_MOVING;
+                features |= F_MOVING;
+            }
+        } else if (p.kind == MIRT_PRIM_RECT) {
+            features |= F_RECT;
+            if (p.axis > MIRT_AXIS_YZ) return bad("prim " + std::to_string(i) + ": rect axis");
+            if (!(p.lo[0] < p.hi[0] && p.lo[1] < p.hi[1])) return bad("prim " + std::to_string(i) + ": rect extents (geo.rs:182)");
+            q.meta = PK_RECT | (p.axis << PM_AXIS_SHIFT);
+            q.a[0] = p.k; q.a[1] = p.lo[0]; q.a[2] = p.hi[0]; q.a[3] = p.lo[1];
+            q.b[0] = p.hi[1];
+            // geo.rs:187-188, 239: the light sample plane is the mid-point of the padded corners
+            float k0 = p.k - 0.0001f, k1 = p.k + 0.0001f;
+            q.b[1] = (k0 + k1) / 2.f;
+        } else if (p.kind == MIRT_PRIM_MEDIUM) {
+            features |= F_MEDIUM;
+            if (p.instance) return bad("prim " + std::to_string(i) + ": a medium takes its transform from its boundary primitives");
+            if ((uint64_t)p.boundary_first + p.boundary_count > d->n_prims || p.boundary_count == 0)
+                return bad("prim " + std::to_string(i) + ": medium boundary range");
+            for (uint32_t b = p.boundary_first; b < p.boundary_first + p.boundary_count; ++b)
+                if (d->prims[b].kind == MIRT_PRIM_MEDIUM) return bad("prim " + std::to_string(i) + ": medium boundary must be spheres / rects");
+            q.meta = PK_MEDIUM;
+            uint32_t idx = n_media++;
+            std::memcpy(&q.a[0], &p.boundary_first, 4);
+            std::memcpy(&q.a[1], &p.boundary_count, 4);
+            q.a[2] = p.neg_inv_density;
+            std::memcpy(&q.a[3], &idx, 4);
+        } else {
+            return bad("prim " + std::to_string(i) + ": unknown kind");
+        }
+        if (p.flags & MIRT_PRIM_FLIP_FACE) q.meta |= PM_FLIP;
+        prims[i] = q;
+    }
+    // ---- materials / textures
+    std::vector<DevMaterial> mats(d->n_materials);
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const mirt_material& m = d->materials[i];
+        DevMaterial q{};
+        q.kind = m.kind;
+        q.texture = m.texture;
+        q.param = m.param;
+        for (int a = 0; a < 3; ++a) q.albedo[a] = m.albedo[a];
+        switch (m.kind) {
+            case MIRT_MAT_LAMBERTIAN: break;
+            case MIRT_MAT_METAL: features |= F_MAT_METAL; break;
+            case MIRT_MAT_DIELECTRIC:
+                features |= F_MAT_DIELECTRIC;
+                if (!(m.param > 0.f)) return bad("material " + std::to_string(i) + ": index of refraction must be > 0 (material.rs:109)");
+                break;
+            case MIRT_MAT_DIFFUSE_LIGHT: features |= F_MAT_LIGHT; break;
+            case MIRT_MAT_ISOTROPIC: features |= F_MAT_ISOTROPIC; break;
+            default: return bad("material " + std::to_string(i) + ": unknown kind");
+        }
+        bool textured = m.kind == MIRT_MAT_LAMBERTIAN || m.kind == MIRT_MAT_DIFFUSE_LIGHT || m.kind == MIRT_MAT_ISOTROPIC;
+        if (textured && m.texture >= d->n_textures) return bad("material " + std::to_string(i) + ": texture index out of range");
+        mats[i] = q;
+    }
+    std::vector<DevTexture> texs(d->n_textures);
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const mirt_texture& t = d->textures[i];
+        DevTexture q{};
+        q.kind = t.kind;
+        q.perlin = t.perlin;
+        q.image = t.image;
+        for (int a = 0; a < 3; ++a) { q.c0[a] = t.color[a]; q.c1[a] = t.color2[a]; }
+        q.c1[3] = t.scale;
+        switch (t.kind) {
+            case MIRT_TEX_SOLID: break;
+            case MIRT_TEX_CHECKER: features |= F_TEX_CHECKER; break;
+            case MIRT_TEX_NOISE:
+                features |= F_TEX_NOISE;
+                if (t.perlin >= d->n_perlins) return bad("texture " + std::to_string(i) + ": perlin index out of range");
+                break;
+            case MIRT_TEX_IMAGE:
+                features |= F_TEX_IMAGE;
+                if (t.image >= d->n_images) return bad("texture " + std::to_string(i) + ": image index out of range");
+                break;
+            default: return bad("texture " + std::to_string(i) + ": unknown kind");
+        }
+        texs[i] = q;
+    }
+    std::vector<DevPerlin> perlins(d->n_perlins);
+    for (uint32_t i = 0; i < d->n_perlins; ++i) {
+        for (int j = 0; j < 256; ++j) {
+            for (int a = 0; a < 3; ++a) perlins[i].grad[j][a] = d->perlins[i].grad[j][a];
+            perlins[i].grad[j][3] = 0.f;
+        }
+        std::memcpy(perlins[i].perm, d->perlins[i].perm, sizeof(perlins[i].perm));
+    }
+    std::vector<DevInstance> insts(std::max<uint32_t>(d->n_instances, 1u));
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+        DevInstance q{};
+        q.sin_t = d->instances[i].sin_theta; q.cos_t = d->instances[i].cos_theta;
+        q.ox = d->instances[i].offset[0]; q.oy = d->instances[i].offset[1]; q.oz = d->instances[i].offset[2];
+        insts[i] = q;
+    }
+    // ---- lights: un-instanced spheres / rects (HittableList of scene.rs:286)
+    std::vector<uint32_t> lights(d->lights, d->lights + d->n_lights);
+    for (uint32_t li : lights) {
+        if (li >= d->n_prims) return bad("light index out of range");
+        if (d->prims[li].kind == MIRT_PRIM_MEDIUM || d->prims[li].instance)
+            return bad("lights must be un-instanced spheres or rects");
+    }
+    // ---- world entries + BVHs
+    std::vector<DevEntry> entries(d->n_world);
+    std::vector<DevBvhNode> nodes;
+    std::vector<uint32_t> slots;
+    for (uint32_t e = 0; e < d->n_world; ++e) {
+        const mirt_entry& w = d->world[e];
+        DevEntry q{};
+        if ((uint64_t)w.first_prim + w.prim_count > d->n_prims) return bad("entry " + std::to_string(e) + ": prim range");
+        if (w.instance && w.instance >= d->n_instances) return bad("entry " + std::to_string(e) + ": instance index out of range");
+        q.first_prim = w.first_prim;
+        q.prim_count = w.prim_count;
+        q.prims_per_object = std::max(1u, w.prims_per_object);
+        q.instance = w.instance;
+        uint32_t kind = w.kind;
+        if (kind == MIRT_ENTRY_LIST) {
+            if (w.instance) return bad("entry " + std::to_string(e) + ": a list entry carries instances on its prims");
+            // A long plain list (the reference scans `random`'s ~488 spheres linearly, ray.rs:123-133)
+            // is traversed through a hierarchy too: the closest hit is the same; only the winner of
+            // an exact tie between two different primitives could differ.
+            bool plain = w.prim_count > 32;
+            for (uint32_t k = 0; plain && k < w.prim_count; ++k) {
+                const mirt_prim& p = d->prims[w.first_prim + k];
+                plain = p.kind != MIRT_PRIM_MEDIUM && p.instance == 0;
+            }
+            if (plain) {
+                kind = MIRT_ENTRY_BVH;
+                q.prims_per_object = 1;
+            }
+        }
+        if (kind == MIRT_ENTRY_LIST) {
+            q.kind = EK_LIST;
+        } else if (kind == MIRT_ENTRY_BVH) {
+            if (w.prim_count == 0) return bad("entry " + std::to_string(e) + ": empty BVH (aabb.rs:98)");
+            if (w.prim_count % q.prims_per_object) return bad("entry " + std::to_string(e) + ": prim_count is not a multiple of prims_per_object");
+            q.kind = EK_BVH;
+            features |= F_BVH;
+            if (w.instance) features |= F_INSTANCE;
+            std::vector<BuildObject> objs(w.prim_count / q.prims_per_object);
+            for (uint32_t j = 0; j < objs.size(); ++j) {
+                BuildObject& o = objs[j];
+                o.first_prim = w.first_prim + j * q.prims_per_object;
+                for (int a = 0; a < 3; ++a) { o.lo[a] = INFINITY; o.hi[a] = -INFINITY; }
+                for (uint32_t k = 0; k < q.prims_per_object; ++k) {
+                    const mirt_prim& p = d->prims[o.first_prim + k];
+                    if (p.kind == MIRT_PRIM_MEDIUM) return bad("entry " + std::to_string(e) + ": media cannot be BVH members");
+                    if (p.instance) return bad("entry " + std::to_string(e) + ": BVH members take the entry's instance");
+                    float lo[3], hi[3];
+                    prim_bounds(p, d->instances, lo, hi);
+                    for (int a = 0; a < 3; ++a) { o.lo[a] = std::min(o.lo[a], lo[a]); o.hi[a] = std::max(o.hi[a], hi[a]); }
+                }
+            }
+            BvhBuilder builder(nodes, slots, 32, q.prims_per_object > 1 ? 1u : 2u);
+            q.bvh_root = builder.build(objs);
+            // the hit record of a BVH member is rebuilt with the entry's transform
+            for (uint32_t k = 0; k < w.prim_count; ++k) prims[w.first_prim + k].instance = w.instance;
+        } else {
+            return bad("entry " + std::to_string(e) + ": unknown kind");
+        }
+        entries[e] = q;
+    }
+    // ---- images
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    std::vector<DevImage> images(d->n_images);
+    for (uint32_t i = 0; i < d->n_images; ++i) {
+        const mirt_image& im = d->images[i];
+        images[i].width = im.rgba ? im.width : 0;
+        images[i].height = im.rgba ? im.height : 0;
+        images[i].rgba = nullptr;
+        if (im.rgba && im.width && im.height) {
+            void* p = nullptr;
+            size_t bytes = (size_t)im.width * im.height * 4;
+            HIP_TRY(c, hipMalloc(&p, bytes));
+            c->scene_allocs.push_back(p);
+            HIP_TRY(c, hipMemcpy(p, im.rgba, bytes, hipMemcpyHostToDevice));
+            images[i].rgba = static_cast<const uint8_t*>(p);
+        } else {
+            images[i].width = images[i].height = 0;
+        }
+    }
+    DevScene s{};
+    int rc;
+    if ((rc = upload(c, prims, &s.prims))) return rc;
+    if ((rc = upload(c, entries, &s.entries))) return rc;
+    if ((rc = upload(c, lights, &s.lights))) return rc;
+    if ((rc = upload(c, mats, &s.materials))) return rc;
+    if ((rc = upload(c, texs, &s.textures))) return rc;
+    if ((rc = upload(c, images, &s.images))) return rc;
+    if ((rc = upload(c, perlins, &s.perlins))) return rc;
+    if ((rc = upload(c, insts, &s.instances))) return rc;
+    if ((rc = upload(c, nodes, &s.bvh_nodes))) return rc;
+    if ((rc = upload(c, slots, &s.bvh_objects))) return rc;
+    s.n_prims = d->n_prims;
+    s.n_entries = d->n_world;
+    s.n_lights = d->n_lights;
+    s.n_media = n_media;
+    s.features = features;
+    for (int a = 0; a < 3; ++a) s.background[a] = d->background[a];
+    c->scene = s;
+    c->has_scene = true;
+    return MIRT_OK;
+}
+
+int mirt_camera_set(mirt_ctx* c, const mirt_camera* cam) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (!cam) return fail(c, MIRT_ERR_INVALID, "mirt_camera_set: cam is NULL");
+    DevCamera q{};
+    for (int a = 0; a < 3; ++a) {
+        q.origin[a] = cam->origin[a]; q.llc[a] = cam->lower_left_corner[a];
+        q.horizontal[a] = cam->horizontal[a]; q.vertical[a] = cam->vertical[a];
+        q.u[a] = cam->u[a]; q.v[a] = cam->v[a];
+    }
+    q.lens_radius = cam->lens_radius; q.time0 = cam->time0; q.time1 = cam->time1;
+    c->cam = q;
+    c->has_camera = true;
+    return MIRT_OK;
+}
+
+int mirt_frame_begin(mirt_ctx* c, uint32_t width, uint32_t height, float* accum_device) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (width < 2 || height < 2) return fail(c, MIRT_ERR_INVALID, "mirt_frame_begin: width and height must be >= 2 (renderer.rs:181-182 divides by width-1, height-1)");
+    if ((uint64_t)width * height > 0x7fffffffull) return fail(c, MIRT_ERR_INVALID, "mirt_frame_begin: frame too large");
+    HIP_TRY(c, hipSetDevice(c->device));
+    size_t pixels = (size_t)width * height;
+    if (accum_device) {
+        c->accum = reinterpret_cast<float4*>(accum_device);
+    } else {
+        if (c->accum_owned_pixels < pixels) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->accum_owned) (void)hipFree(c->accum_owned);
+            c->accum_owned = nullptr;
+            c->accum_owned_pixels = 0;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->accum_owned), pixels * sizeof(float4)));
+            c->accum_owned_pixels = pixels;
+        }
+        c->accum = c->accum_owned;
+    }
+    c->width = width;
+    c->height = height;
+    HIP_TRY(c, hipMemsetAsync(c->accum, 0, pixels * sizeof(float4), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->seg_counter, 0, sizeof(unsigned long long), c->stream));
+    c->stats = mirt_stats{};
+    return MIRT_OK;
+}
+
+int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (!p) return fail(c, MIRT_ERR_INVALID, "mirt_render: params is NULL");
+    if (!c->has_scene) return fail(c, MIRT_ERR_STATE, "mirt_render: no scene uploaded");
+    if (!c->has_camera) return fail(c, MIRT_ERR_STATE, "mirt_render: no camera set");
+    if (!c->accum || p->width != c->width || p->height != c->height)
+        return fail(c, MIRT_ERR_STATE, "mirt_render: width/height differ from mirt_frame_begin");
+    if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, "mirt_render: sample range overflows 32 bits");
+    if (p->kernel == MIRT_KERNEL_WAVEFRONT) return fail(c, MIRT_ERR_INVALID, "mirt_render: wavefront kernel set not built in this version");
+    HIP_TRY(c, hipSetDevice(c->device));
+    RenderArgs a{};
+    a.scene = c->scene;
+    a.cam = c->cam;
+    a.width = p->width; a.height = p->height;
+    a.max_depth = p->max_depth; a.seed = p->seed; a.jitter = p->jitter;
+    a.accum = c->accum;
+    a.segment_counter = c->seg_counter;
+    // Long renders are cut into launches of at most kChunk samples per pixel: lanes of a wave
+    // then finish within a few percent of each other and no launch runs for seconds.
+    const uint32_t kChunk = 256;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    uint32_t launches = 0;
+    for (uint32_t done = 0; done < p->spp_count; done += kChunk) {
+        a.spp_begin = p->spp_begin + done;
+        a.spp_count = std::min(kChunk, p->spp_count - done);
+        HIP_TRY(c, launch_render_fused(a, c->stream));
+        ++launches;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->stats.samples += (uint64_t)p->width * p->height * p->spp_count;
+    c->stats.kernel_launches = launches;
+    c->stats.kernel_used = MIRT_KERNEL_FUSED;
+    return MIRT_OK;
+}
+
+int mirt_resolve_rgba8_device(mirt_ctx* c, uint8_t* frame_device, size_t len) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (!c->accum) return fail(c, MIRT_ERR_STATE, "mirt_resolve_rgba8: no frame begun");
+    if (!frame_device) return fail(c, MIRT_ERR_INVALID, "mirt_resolve_rgba8: frame is NULL");
+    if (len != (size_t)c->width * c->height * 4) return fail(c, MIRT_ERR_INVALID, "mirt_resolve_rgba8: len != width*height*4 (renderer.rs:65)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, launch_resolve_rgba8(c->accum, frame_device, c->width, c->height, c->stream));
+    return MIRT_OK;
+}
+
+int mirt_resolve_rgba8(mirt_ctx* c, uint8_t* frame, size_t len) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (!c->accum) return fail(c, MIRT_ERR_STATE, "mirt_resolve_rgba8: no frame begun");
+    if (!frame) return fail(c, MIRT_ERR_INVALID, "mirt_resolve_rgba8: frame is NULL");
+    if (len != (size_t)c->width * c->height * 4) return fail(c, MIRT_ERR_INVALID, "mirt_resolve_rgba8: len != width*height*4 (renderer.rs:65)");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->frame_dev_bytes < len) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->frame_dev) (void)hipFree(c->frame_dev);
+        c->frame_dev = nullptr;
+        c->frame_dev_bytes = 0;
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->frame_dev), len));
+        c->frame_dev_bytes = len;
+    }
+    HIP_TRY(c, launch_resolve_rgba8(c->accum, c->frame_dev, c->width, c->height, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(frame, c->frame_dev, len, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MIRT_OK;
+}
+
+int mirt_read_accum(mirt_ctx* c, float* rgba, size_t n) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (!c->accum) return fail(c, MIRT_ERR_STATE, "mirt_read_accum: no frame begun");
+    if (!rgba || n != (size_t)c->width * c->height * 4) return fail(c, MIRT_ERR_INVALID, "mirt_read_accum: n != width*height*4");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(rgba, c->accum, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MIRT_OK;
+}
+
+int mirt_accum_device_ptr(mirt_ctx* c, float** out) {
+    if (!c || !out) return MIRT_ERR_INVALID;
+    if (!c->accum) return fail(c, MIRT_ERR_STATE, "mirt_accum_device_ptr: no frame begun");
+    *out = reinterpret_cast<float*>(c->accum);
+    return MIRT_OK;
+}
+
+static int ray_batch(mirt_ctx* c, const mirt_ray* rays, size_t n, bool color, uint32_t sample, uint32_t max_depth, uint32_t seed,
+                     int32_t* prim_id, float* t, float* aov, float* out) {
+    if (!c->has_scene) return fail(c, MIRT_ERR_STATE, "no scene uploaded");
+    if (n == 0) return MIRT_OK;
+    if (!rays) return fail(c, MIRT_ERR_INVALID, "rays is NULL");
+    if (n > 0x7fffffffull) return fail(c, MIRT_ERR_INVALID, "too many rays");
+    HIP_TRY(c, hipSetDevice(c->device));
+    static_assert(sizeof(mirt_ray) == 7 * sizeof(float), "mirt_ray is 7 packed floats");
+    float *d_rays = nullptr, *d_t = nullptr, *d_aov = nullptr, *d_out = nullptr;
+    int32_t* d_id = nullptr;
+    int rc = MIRT_OK;
+    auto cleanup = [&]() {
+        if (d_rays) (void)hipFree(d_rays);
+        if (d_t) (void)hipFree(d_t);
+        if (d_aov) (void)hipFree(d_aov);
+        if (d_out) (void)hipFree(d_out);
+        if (d_id) (void)hipFree(d_id);
+    };
+#define RB_TRY(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) { cleanup(); return fail(c, MIRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    RB_TRY(hipMalloc(reinterpret_cast<void**>(&d_rays), n * sizeof(mirt_ray)));
+    RB_TRY(hipMemcpyAsync(d_rays, rays, n * sizeof(mirt_ray), hipMemcpyHostToDevice, c->stream));
+    RayBatchArgs a{};
+    a.scene = c->scene;
+    a.rays = d_rays;
+    a.n = (uint32_t)n;
+    a.sample = sample; a.max_depth = max_depth; a.seed = seed;
+    if (color) {
+        RB_TRY(hipMalloc(reinterpret_cast<void**>(&d_out), n * 3 * sizeof(float)));
+        a.color = d_out;
+        RB_TRY(launch_ray_color(a, c->stream));
+        RB_TRY(hipMemcpyAsync(out, d_out, n * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    } else {
+        RB_TRY(hipMalloc(reinterpret_cast<void**>(&d_id), n * sizeof(int32_t)));
+        RB_TRY(hipMalloc(reinterpret_cast<void**>(&d_t), n * sizeof(float)));
+        if (aov) RB_TRY(hipMalloc(reinterpret_cast<void**>(&d_aov), n * 12 * sizeof(float)));
+        a.prim_id = d_id; a.t = d_t; a.aov = d_aov;
+        RB_TRY(launch_first_hit(a, c->stream));
+        RB_TRY(hipMemcpyAsync(prim_id, d_id, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        RB_TRY(hipMemcpyAsync(t, d_t, n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (aov) RB_TRY(hipMemcpyAsync(aov, d_aov, n * 12 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    }
+    RB_TRY(hipStreamSynchronize(c->stream));
+#undef RB_TRY
+    cleanup();
+    return rc;
+}
+
+int mirt_first_hit(mirt_ctx* c, const mirt_ray* rays, size_t n, uint32_t seed, int32_t* prim_id, float* t, float* aov) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (n && (!prim_id || !t)) return fail(c, MIRT_ERR_INVALID, "mirt_first_hit: output is NULL");
+    return ray_batch(c, rays, n, false, 0, 0, seed, prim_id, t, aov, nullptr);
+}
+
+int mirt_ray_color(mirt_ctx* c, const mirt_ray* rays, size_t n, uint32_t sample, uint32_t max_depth, uint32_t seed, float* out) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (n && !out) return fail(c, MIRT_ERR_INVALID, "mirt_ray_color: out is NULL");
+    return ray_batch(c, rays, n, true, sample, max_depth, seed, nullptr, nullptr, nullptr, out);
+}
+
+int mirt_synchronize(mirt_ctx* c) {
+    if (!c) return MIRT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MIRT_OK;
+}
+
+int mirt_get_stats(mirt_ctx* c, mirt_stats* out) {
+    if (!c || !out) return MIRT_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long seg = 0;
+    HIP_TRY(c, hipMemcpy(&seg, c->seg_counter, sizeof(seg), hipMemcpyDeviceToHost));
+    c->stats.segments = seg;
+    if (c->stats.kernel_launches) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.kernel_ms = ms;
+    }
+    *out = c->stats;
+    return MIRT_OK;
+}
+
+void mirt_philox4x32_10(const uint32_t key[2], const uint32_t ctr[4], uint32_t out[4]) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)M0 * c0, p1 = (uint64_t)M1 * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1; c3 = (uint32_t)p0; c0 = n0; c2 = n2;
+        k0 += W0; k1 += W1;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+}  // extern "C"
