@@ -55,6 +55,7 @@ def main():
 
     import torch
     import ray_tracing_amd as rt
+    from ray_tracing_amd.distributed import reduce_accum, weak_range
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -77,10 +78,11 @@ def main():
 
     def step():
         ctx.frame_begin(W, H, accum.data_ptr())
-        ctx.render(spp, args.depth, spp_begin=rank * spp, seed=0, jitter=True)
+        begin, count = weak_range(spp, rank)
+        ctx.render(count, args.depth, spp_begin=begin, seed=0, jitter=True)
         if world > 1:
             ctx.synchronize()                       # the render runs on the library's own stream
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+            reduce_accum(accum, dst=0)              # RCCL sum of the float4 buffers onto rank 0
             torch.cuda.synchronize()
         if rank == 0:
             ctx.resolve_rgba8_device(frame.data_ptr(), frame.numel())

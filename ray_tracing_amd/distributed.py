@@ -1,0 +1,27 @@
+"""Multi-GPU split of the sample loop: one process per GPU, each renders a contiguous range of the
+samples of every pixel; the float4 accumulation buffers are summed with one collective (RCCL when the
+process group's backend is "nccl"). The Philox key holds the GLOBAL sample index, so the ranks' streams
+are disjoint and the reduced image equals a single-GPU render of all samples up to fp32 reassociation."""
+
+
+def sample_range(total_spp, world_size, rank):
+    """Strong split: contiguous, balanced (sizes differ by at most one) partition of [0, total_spp)."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(int(total_spp), int(world_size))
+    begin = rank * base + min(rank, extra)
+    return begin, base + (1 if rank < extra else 0)
+
+
+def weak_range(spp_per_rank, rank):
+    """Weak split: every rank renders spp_per_rank samples, rank r owning [r*spp, (r+1)*spp)."""
+    return rank * int(spp_per_rank), int(spp_per_rank)
+
+
+def reduce_accum(accum, dst=0, group=None):
+    """Sum the per-rank accumulation buffers (torch tensors of width*height*4 floats: sum r, g, b and the
+    sample count) onto rank `dst`. The only exchange step of the path."""
+    import torch.distributed as dist
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return accum
