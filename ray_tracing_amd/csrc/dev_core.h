@@ -4,6 +4,14 @@
 //
 // Template parameter F (a mask of mirt::F_* bits) strips the code a scene does not need, so the
 // Cornell-box kernel carries no BVH stack, medium, Perlin or image-texture code.
+//
+// Arithmetic policy. Everything that decides WHICH primitive a ray hits and at what t (ray
+// transforms, plane / sphere roots, extent tests) is evaluated with separately rounded IEEE
+// operations in the reference's order, so first-hit ids agree exactly with a CPU evaluation; the
+// one liberty is that the plane division uses a shared reciprocal plus one Newton step (result
+// correctly rounded except with probability ~2^-21). Shading (sampling directions, pdfs,
+// throughput) uses the hardware approximations v_rcp / v_rsq / v_sqrt / v_sin / v_cos, which
+// perturb a sample by ~1e-6 relative and leave the estimator's expectation unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
@@ -35,11 +43,40 @@ MIRT_DEV V3 normalize(V3 a) { return a / sqrtf(norm_squared(a)); }
 MIRT_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 MIRT_DEV float comp(V3 v, uint32_t i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 
+// hardware approximations (about 1 ulp) for the shading code
+MIRT_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+MIRT_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+MIRT_DEV float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+MIRT_DEV V3 fast_normalize(V3 a) { return a * fast_rsq(norm_squared(a)); }
+// sin / cos of 2*pi*u for u in [0, 1): v_sin_f32 / v_cos_f32 take their argument in revolutions
+MIRT_DEV void sincos_2pi(float u, float& sn, float& cs) {
+    sn = __builtin_amdgcn_sinf(u);
+    cs = __builtin_amdgcn_cosf(u);
+}
+// n / d from r = v_rcp(d) and one Newton step; NaN when d == 0 (callers reject NaN)
+MIRT_DEV float div_nr(float n, float d, float r) {
+    float q = n * r;
+    float e = __builtin_fmaf(-q, d, n);
+    return __builtin_fmaf(e, r, q);
+}
+
 struct Ray {
     V3 o, d;
     float time;
 };
 MIRT_DEV V3 ray_at(const Ray& r, float t) { return r.o + t * r.d; }
+
+// A ray in the frame of the primitives being tested plus the reciprocals of its direction.
+struct LRay {
+    Ray r;
+    V3 rinv;
+};
+MIRT_DEV LRay make_lray(const Ray& r) {
+    LRay l;
+    l.r = r;
+    l.rinv = v3(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+    return l;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Philox4x32-10 draw streams (stands in for rand::random::<f32>() of rand_gen.rs:7-17)
@@ -69,16 +106,26 @@ MIRT_DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, 
 
 MIRT_DEV float unit_f32(uint32_t w) { return (float)(w >> 8) * (1.0f / 16777216.0f); }
 
+// Sequential draws of one stream. `have` is the index of the block held in w0..w3.
 struct Rng {
     uint32_t k0, k1, c1, c2, c3;
-    uint32_t pos;
+    uint32_t pos, have;
     uint32_t w0, w1, w2, w3;
     MIRT_DEV void init(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stream, uint32_t seed) {
-        k0 = pixel; k1 = sample; c1 = bounce; c2 = stream; c3 = seed; pos = 0;
+        k0 = pixel; k1 = sample; c1 = bounce; c2 = stream; c3 = seed; pos = 0; have = 0xffffffffu;
+    }
+    // start the stream with block 0 already generated by the caller
+    MIRT_DEV void init_with_block0(uint32_t pixel, uint32_t sample, uint32_t bounce, uint32_t stream, uint32_t seed, uint32_t b0,
+                                   uint32_t b1, uint32_t b2, uint32_t b3) {
+        init(pixel, sample, bounce, stream, seed);
+        have = 0; w0 = b0; w1 = b1; w2 = b2; w3 = b3;
     }
     MIRT_DEV float next() {
-        uint32_t i = pos & 3u;
-        if (i == 0) philox4x32_10(k0, k1, pos >> 2, c1, c2, c3, w0, w1, w2, w3);
+        uint32_t blk = pos >> 2, i = pos & 3u;
+        if (blk != have) {
+            philox4x32_10(k0, k1, blk, c1, c2, c3, w0, w1, w2, w3);
+            have = blk;
+        }
         uint32_t w = i == 0 ? w0 : (i == 1 ? w1 : (i == 2 ? w2 : w3));
         ++pos;
         return unit_f32(w);
@@ -109,13 +156,11 @@ MIRT_DEV V3 rand_in_unit_disk(Rng& g) {
 }
 // rand_gen.rs:80-90 — r2 in [0, 0.9): z >= sqrt(0.1).
 MIRT_DEV V3 random_cosine_direction(float xi1, float xi2) {
-    float r1 = xi1;
     float r2 = 0.f + (0.9f - 0.f) * xi2;
-    float z = sqrtf(1.f - r2);
-    float phi = 2.f * kPi * r1;
-    float r2_sq = sqrtf(r2);
+    float z = fast_sqrt(1.f - r2);
+    float r2_sq = fast_sqrt(r2);
     float sn, cs;
-    sincosf(phi, &sn, &cs);
+    sincos_2pi(xi1, sn, cs);  // phi = 2*pi*r1
     return v3(cs * r2_sq, sn * r2_sq, z);
 }
 
@@ -149,6 +194,15 @@ MIRT_DEV Ray to_local(const DevInstance& in, const Ray& r) {
     l.time = r.time;
     return l;
 }
+
+// Tables that shading reads with a per-lane (divergent) index. They point either at the scene's
+// global arrays or at the block's LDS copies (small scenes).
+struct Tables {
+    const DevPrim* prims;
+    const DevInstance* instances;
+    const DevMaterial* materials;
+    const DevTexture* textures;
+};
 
 // ---------------------------------------------------------------------------------------------
 // primitives
@@ -190,26 +244,26 @@ MIRT_DEV void axis_indexes(uint32_t axis, uint32_t& xi, uint32_t& yi, uint32_t& 
     zi = axis == 0 ? 2u : (axis == 1 ? 1u : 0u);
 }
 
-// geo.rs:196-204 — zero-thickness plane, inclusive range and extent tests.
-MIRT_DEV bool rect_hit(const DevPrim& p, const Ray& r, float t_min, float t_max, float& t_out) {
+// geo.rs:196-204 — zero-thickness plane, inclusive range and extent tests. Written in accepting
+// form so that a NaN t (direction parallel to the plane) is a miss.
+MIRT_DEV bool rect_hit(const DevPrim& p, const LRay& l, float t_min, float t_max, float& t_out) {
     uint32_t xi, yi, zi;
     axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
     float k = p.a[0];
-    float t = (k - comp(r.o, zi)) / comp(r.d, zi);
-    if (t < t_min || t > t_max) return false;
-    float x = comp(r.o, xi) + t * comp(r.d, xi);
-    float y = comp(r.o, yi) + t * comp(r.d, yi);
-    if (x < p.a[1] || x > p.a[2] || y < p.a[3] || y > p.b[0]) return false;
+    float t = div_nr(k - comp(l.r.o, zi), comp(l.r.d, zi), comp(l.rinv, zi));
+    float x = comp(l.r.o, xi) + t * comp(l.r.d, xi);
+    float y = comp(l.r.o, yi) + t * comp(l.r.d, yi);
+    bool h = (t >= t_min) & (t <= t_max) & (x >= p.a[1]) & (x <= p.a[2]) & (y >= p.a[3]) & (y <= p.b[0]);
     t_out = t;
-    return true;
+    return h;
 }
 
 template <uint32_t F>
-MIRT_DEV bool leaf_hit(const DevPrim& p, const Ray& r, float t_min, float t_max, float& t_out) {
+MIRT_DEV bool leaf_hit(const DevPrim& p, const LRay& l, float t_min, float t_max, float& t_out) {
     uint32_t kind = p.meta & PM_KIND_MASK;
     if ((F & F_SPHERE) && (!(F & F_RECT) || kind == PK_SPHERE))
-        return sphere_hit_c(sphere_center<F>(p, r.time), p.a[3], r, t_min, t_max, t_out);
-    if ((F & F_RECT) && kind == PK_RECT) return rect_hit(p, r, t_min, t_max, t_out);
+        return sphere_hit_c(sphere_center<F>(p, l.r.time), p.a[3], l.r, t_min, t_max, t_out);
+    if ((F & F_RECT) && kind == PK_RECT) return rect_hit(p, l, t_min, t_max, t_out);
     return false;
 }
 
@@ -218,29 +272,42 @@ struct DrawKey {
     uint32_t pixel, sample, bounce, seed;
 };
 
-// HittableList::hit (ray.rs:123-133) over prims [first, first+count) whose indices are
-// wave-uniform: `t <= closest` accepts, so the later primitive wins a tie. Sphere / rect only
-// (used for the boundaries of constant media and, through list_scan, for the world).
 template <uint32_t F>
-MIRT_DEV void boundary_scan(const DevScene& s, uint32_t first, uint32_t count, const Ray& r, float t_min, float& closest,
-                            int& best) {
+MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, float t_min, float t_max, const DrawKey& key,
+                         float& t_out);
+
+// HittableList::hit (ray.rs:123-133) over prims [first, first+count) whose indices are
+// wave-uniform: `t <= closest` accepts, so the later primitive wins a tie. The primitive record
+// of the next iteration is fetched (scalar loads) while the current one is tested.
+template <uint32_t F, bool ALLOW_MEDIUM>
+MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const Ray& r, float t_min, const DrawKey& key,
+                        float& closest, int& best) {
+    if (count == 0) return;
     uint32_t cur_inst = 0;
-    Ray lr = r;
-    for (uint32_t i = first; i < first + count; ++i) {
-        const DevPrim& p = s.prims[i];
-        if (F & F_INSTANCE) {
-            uint32_t inst = p.instance;
-            if (inst != cur_inst) {
-                cur_inst = inst;
-                lr = r;
-                if (inst) lr = to_local(s.instances[inst], r);
-            }
-        }
+    LRay lr = make_lray(r);
+    const uint32_t last = first + count - 1;
+    DevPrim p = s.prims[first];
+    for (uint32_t i = first; i <= last; ++i) {
+        DevPrim nxt = s.prims[i < last ? i + 1 : last];
         float t;
-        if (leaf_hit<F>(p, lr, t_min, closest, t)) {
+        bool h;
+        if (ALLOW_MEDIUM && (F & F_MEDIUM) && (p.meta & PM_KIND_MASK) == PK_MEDIUM) {
+            h = medium_hit<F>(s, p, r, t_min, closest, key, t);
+        } else {
+            if (F & F_INSTANCE) {
+                uint32_t inst = p.instance;
+                if (inst != cur_inst) {
+                    cur_inst = inst;
+                    lr = make_lray(inst ? to_local(s.instances[inst], r) : r);
+                }
+            }
+            h = leaf_hit<F>(p, lr, t_min, closest, t);
+        }
+        if (h) {
             closest = t;
             best = (int)i;
         }
+        p = nxt;
     }
 }
 
@@ -251,10 +318,10 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
     uint32_t bfirst = __float_as_uint(p.a[0]), bcount = __float_as_uint(p.a[1]);
     float t1 = MIRT_INF, t2 = MIRT_INF;
     int b = -1;
-    boundary_scan<F>(s, bfirst, bcount, r, -MIRT_INF, t1, b);
+    list_scan<F, false>(s, bfirst, bcount, r, -MIRT_INF, key, t1, b);
     if (b < 0) return false;
     b = -1;
-    boundary_scan<F>(s, bfirst, bcount, r, t1 + 0.0001f, t2, b);
+    list_scan<F, false>(s, bfirst, bcount, r, t1 + 0.0001f, key, t2, b);
     if (b < 0) return false;
     t1 = fmaxf(fmaxf(t_min, t1), 0.f);
     t2 = fminf(t_max, t2);
@@ -266,36 +333,6 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
     if (hit_distance > distance_inside_boundary) return false;
     t_out = t1 + hit_distance;
     return true;
-}
-
-// World-list scan with media allowed (scene.rs:290 world list through ray.rs:123-133).
-template <uint32_t F>
-MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const Ray& r, float t_min, const DrawKey& key,
-                        float& closest, int& best) {
-    uint32_t cur_inst = 0;
-    Ray lr = r;
-    for (uint32_t i = first; i < first + count; ++i) {
-        const DevPrim& p = s.prims[i];
-        float t;
-        bool h;
-        if ((F & F_MEDIUM) && (p.meta & PM_KIND_MASK) == PK_MEDIUM) {
-            h = medium_hit<F>(s, p, r, t_min, closest, key, t);
-        } else {
-            if (F & F_INSTANCE) {
-                uint32_t inst = p.instance;
-                if (inst != cur_inst) {
-                    cur_inst = inst;
-                    lr = r;
-                    if (inst) lr = to_local(s.instances[inst], r);
-                }
-            }
-            h = leaf_hit<F>(p, lr, t_min, closest, t);
-        }
-        if (h) {
-            closest = t;
-            best = (int)i;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,7 +352,7 @@ MIRT_DEV bool slab(const float* lo, const float* hi, V3 o, V3 inv_d, float t_min
 }
 
 template <uint32_t F>
-MIRT_DEV void bvh_leaf(const DevScene& s, const DevEntry& en, uint32_t slot, uint32_t n, const Ray& lr, float t_min,
+MIRT_DEV void bvh_leaf(const DevScene& s, const DevEntry& en, uint32_t slot, uint32_t n, const LRay& lr, float t_min,
                        float& closest, int& best) {
     for (uint32_t j = 0; j < n; ++j) {
         uint32_t first = s.bvh_objects[slot + j];
@@ -335,16 +372,15 @@ MIRT_DEV void bvh_leaf(const DevScene& s, const DevEntry& en, uint32_t slot, uin
 template <uint32_t F>
 MIRT_DEV void bvh_traverse(const DevScene& s, const DevEntry& en, const Ray& r, float t_min, float& closest, int& best,
                            uint32_t* stack, uint32_t stride) {
-    Ray lr = r;
-    if ((F & F_INSTANCE) && en.instance) lr = to_local(s.instances[en.instance], r);
-    V3 inv_d = v3(1.f / lr.d.x, 1.f / lr.d.y, 1.f / lr.d.z);
+    LRay lr = make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
+    V3 inv_d = v3(1.f / lr.r.d.x, 1.f / lr.r.d.y, 1.f / lr.r.d.z);
     uint32_t sp = 0;
     uint32_t node = en.bvh_root;
     for (;;) {
         const DevBvhNode& nd = s.bvh_nodes[node];
         float tn0, tn1;
-        bool h0 = slab(nd.lo0, nd.hi0, lr.o, inv_d, t_min, closest, tn0);
-        bool h1 = nd.c1 != 0xffffffffu && slab(nd.lo1, nd.hi1, lr.o, inv_d, t_min, closest, tn1);
+        bool h0 = slab(nd.lo0, nd.hi0, lr.r.o, inv_d, t_min, closest, tn0);
+        bool h1 = nd.c1 != 0xffffffffu && slab(nd.lo1, nd.hi1, lr.r.o, inv_d, t_min, closest, tn1);
         uint32_t c0 = nd.c0, n0 = nd.n0, c1 = nd.c1, n1 = nd.n1;
         // leaves are intersected immediately; interior children are visited near-first
         if (h0 && n0) {
@@ -380,7 +416,7 @@ MIRT_DEV void world_hit(const DevScene& s, const Ray& r, const DrawKey& key, uin
         if ((F & F_BVH) && en.kind == EK_BVH)
             bvh_traverse<F>(s, en, r, 0.001f, closest, best, stack, stride);
         else
-            list_scan<F>(s, en.first_prim, en.prim_count, r, 0.001f, key, closest, best);
+            list_scan<F, true>(s, en.first_prim, en.prim_count, r, 0.001f, key, closest, best);
     }
     t_out = closest;
     prim_out = best;
@@ -397,8 +433,8 @@ struct HitInfo {
 };
 
 template <uint32_t F>
-MIRT_DEV HitInfo finalize_hit(const DevScene& s, const Ray& r, float t, int prim) {
-    const DevPrim& p = s.prims[prim];
+MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim) {
+    const DevPrim& p = tb.prims[prim];
     HitInfo h;
     h.material = p.material;
     h.u = 0.f;
@@ -413,20 +449,20 @@ MIRT_DEV HitInfo finalize_hit(const DevScene& s, const Ray& r, float t, int prim
     }
     Ray lr = r;
     uint32_t inst = (F & F_INSTANCE) ? p.instance : 0u;
-    if (inst) lr = to_local(s.instances[inst], r);
+    if (inst) lr = to_local(tb.instances[inst], r);
     V3 pl = ray_at(lr, t);
     V3 nl;
     bool front;
     if ((F & F_SPHERE) && (!(F & F_RECT) || kind == PK_SPHERE)) {
         // geo.rs:108-111
-        V3 outward = (pl - sphere_center<F>(p, lr.time)) / p.a[3];
+        V3 outward = (pl - sphere_center<F>(p, lr.time)) * fast_rcp(p.a[3]);
         if (F & F_TEX_IMAGE) {
             float theta = acosf(-outward.y);                    // geo.rs:71-75
             float phi = atan2f(-outward.z, outward.x) + kPi;
             h.u = phi / (2.f * kPi);
             h.v = theta / kPi;
         }
-        V3 on = normalize(outward);
+        V3 on = fast_normalize(outward);
         front = dot(lr.d, on) < 0.f;
         nl = front ? on : -on;
     } else {
@@ -443,7 +479,7 @@ MIRT_DEV HitInfo finalize_hit(const DevScene& s, const Ray& r, float t, int prim
     }
     if (p.meta & PM_FLIP) front = !front;  // geo.rs:455-459: the flag flips, the normal does not
     if (inst) {
-        const DevInstance& in = s.instances[inst];
+        const DevInstance& in = tb.instances[inst];
         h.p = rot_y(in, pl) + v3(in.ox, in.oy, in.oz);  // geo.rs:377-380 then geo.rs:309
         h.n = rot_y(in, nl);
     } else {
@@ -499,8 +535,8 @@ MIRT_DEV float perlin_turb(const DevPerlin& pl, V3 p) {
 }
 
 template <uint32_t F>
-MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 p) {
-    const DevTexture& t = s.textures[tex];
+MIRT_DEV V3 texture_value(const DevScene& s, const Tables& tb, uint32_t tex, float u, float v, V3 p) {
+    const DevTexture& t = tb.textures[tex];
     uint32_t kind = t.kind;
     if ((F & F_TEX_CHECKER) && kind == TK_CHECKER) {
         // texture.rs:42-46
@@ -533,38 +569,49 @@ MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 
 // light list: HittableList::{pdf_val, random} (ray.rs:149-154) over scene.lights
 // ---------------------------------------------------------------------------------------------
 // geo.rs:223-233 (rect) and geo.rs:136-143 (sphere). Instances are not applied and FlipFace is
-// transparent, as in geo.rs:324-329 and geo.rs:465-470.
+// transparent, as in geo.rs:324-329 and geo.rs:465-470. `p` is wave-uniform (scalar registers).
 template <uint32_t F>
-MIRT_DEV float light_pdf_one(const DevPrim& p, V3 origin, V3 v) {
+MIRT_DEV float light_pdf_one(const DevPrim& p, V3 origin, V3 v, V3 vinv) {
     uint32_t kind = p.meta & PM_KIND_MASK;
     if ((F & F_RECT) && kind == PK_RECT) {
-        Ray pr{origin, v, 0.2f};
-        float t;
-        if (!rect_hit(p, pr, 0.001f, MIRT_INF, t)) return 0.f;
         uint32_t xi, yi, zi;
         axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
+        float t = (p.a[0] - comp(origin, zi)) * comp(vinv, zi);
+        float x = comp(origin, xi) + t * comp(v, xi);
+        float y = comp(origin, yi) + t * comp(v, yi);
+        bool h = (t >= 0.001f) & (x >= p.a[1]) & (x <= p.a[2]) & (y >= p.a[3]) & (y <= p.b[0]);
         float area = fabsf((p.a[2] - p.a[1]) * (p.b[0] - p.a[3]));
         float dis_squared = t * t * norm_squared(v);
         float cosine = fabsf(comp(v, zi));
-        return dis_squared / (cosine * area);
+        return h ? dis_squared * fast_rcp(cosine * area) : 0.f;
     }
     if ((F & F_SPHERE) && kind == PK_SPHERE) {
-        Ray pr{origin, v, 0.f};
-        float t;
-        if (!sphere_hit_c(sphere_center<F>(p, 0.f), p.a[3], pr, 0.001f, MIRT_INF, t)) return 0.f;
+        // probe ray at time 0 (geo.rs:137); nearest root in [0.001, inf)
+        V3 c = sphere_center<F>(p, 0.f);
+        float radius = p.a[3];
+        V3 oc = origin - c;
+        float a = norm_squared(v);
+        float half_b = dot(oc, v);
+        float cc = norm_squared(oc) - radius * radius;
+        float disc = half_b * half_b - a * cc;
+        float sqrtd = fast_sqrt(disc);
+        float ra = fast_rcp(a);
+        float root0 = (-half_b - sqrtd) * ra, root1 = (-half_b + sqrtd) * ra;
+        bool h = (disc >= 0.f) & ((root0 >= 0.001f) | (root1 >= 0.001f));
         V3 c0 = v3(p.a[0], p.a[1], p.a[2]);
-        float cos_theta_max = sqrtf(1.f - p.a[3] * p.a[3] / norm_squared(c0 - origin));
+        float cos_theta_max = fast_sqrt(1.f - radius * radius * fast_rcp(norm_squared(c0 - origin)));
         float solid_angle = 2.f * kPi * (1.f - cos_theta_max);
-        return 1.f / solid_angle;
+        return h ? fast_rcp(solid_angle) : 0.f;  // NaN when the origin is inside the sphere (geo.rs:138)
     }
     return 0.f;
 }
 
 template <uint32_t F>
 MIRT_DEV float lights_pdf(const DevScene& s, V3 origin, V3 v) {
+    V3 vinv = v3(fast_rcp(v.x), fast_rcp(v.y), fast_rcp(v.z));
     float sum = 0.f;
-    for (uint32_t i = 0; i < s.n_lights; ++i) sum += light_pdf_one<F>(s.prims[s.lights[i]], origin, v);
-    return sum / (float)s.n_lights;
+    for (uint32_t i = 0; i < s.n_lights; ++i) sum += light_pdf_one<F>(s.prims[s.lights[i]], origin, v, vinv);
+    return sum * fast_rcp((float)s.n_lights);
 }
 
 // geo.rs:234-242 (rect) and geo.rs:144-149 with geo.rs:77-85 (sphere): two draws each.
@@ -578,96 +625,81 @@ MIRT_DEV V3 light_random_one(const DevPrim& p, V3 origin, float xi1, float xi2) 
         float b = p.a[3] + (p.b[0] - p.a[3]) * xi2;
         float k = p.b[1];
         V3 pt = v3(xi == 0 ? a : (yi == 0 ? b : k), xi == 1 ? a : (yi == 1 ? b : k), xi == 2 ? a : (yi == 2 ? b : k));
-        return normalize(pt - origin);
+        return fast_normalize(pt - origin);
     }
     if ((F & F_SPHERE) && kind == PK_SPHERE) {
         V3 c0 = v3(p.a[0], p.a[1], p.a[2]);
         V3 direction = c0 - origin;
         float d = norm_squared(direction);
-        Onb uvw = onb_from_w(normalize(direction));
-        float r1 = xi1, r2 = xi2;
-        float z = 1.f + r2 * (sqrtf(1.f - p.a[3] * p.a[3] / d) - 1.f);
-        float phi = 2.f * kPi * r1;
+        Onb uvw = onb_from_w(direction * fast_rsq(d));
+        float z = 1.f + xi2 * (fast_sqrt(1.f - p.a[3] * p.a[3] * fast_rcp(d)) - 1.f);
         float sn, cs;
-        sincosf(phi, &sn, &cs);
-        float x = cs * sqrtf(1.f - z * z);
-        float y = sn * sqrtf(1.f - z * z);
-        return onb_local(uvw, v3(x, y, z));
+        sincos_2pi(xi1, sn, cs);
+        float s1 = fast_sqrt(1.f - z * z);
+        return onb_local(uvw, v3(cs * s1, sn * s1, z));
     }
     return v3(1.f, 0.f, 0.f);  // ray.rs:41-43
 }
 
 // ---------------------------------------------------------------------------------------------
-// one level of ray_color (renderer.rs:197-237) after world.hit found `prim` at `t`
+// one level of ray_color (renderer.rs:197-237) after world.hit found a primitive
 // ---------------------------------------------------------------------------------------------
-enum ShadeResult { SHADE_CONTINUE = 0, SHADE_TERMINATE = 1 };
-
-// On SHADE_CONTINUE: `ray` is the scattered ray and `thr` has been multiplied by
-// attenuation / divisor. On SHADE_TERMINATE: `radiance` is what this level returns to its caller
-// (emission, or 0 when the ray is absorbed), not yet multiplied by thr.
+// material.rs:167-175: a DiffuseLight never scatters and emits toward front_face only.
 template <uint32_t F>
-MIRT_DEV ShadeResult shade(const DevScene& s, Ray& ray, float t, int prim, const DrawKey& key, V3& thr, V3& radiance) {
-    HitInfo h = finalize_hit<F>(s, ray, t, prim);
-    const DevMaterial& m = s.materials[h.material];
-    uint32_t mk = m.kind;
-    radiance = v3(0.f, 0.f, 0.f);
-    Rng g;
-    g.init(key.pixel, key.sample, key.bounce, STREAM_SCATTER, key.seed);
+MIRT_DEV V3 emitted_radiance(const DevScene& s, const Tables& tb, const DevMaterial& m, const HitInfo& h) {
+    if (h.front) return texture_value<F>(s, tb, m.texture, h.u, h.v, h.p);
+    return v3(0.f, 0.f, 0.f);
+}
 
-    if ((F & F_MAT_LIGHT) && mk == MK_DIFFUSE_LIGHT) {
-        // material.rs:167-175: never scatters, emits toward front_face only
-        if (h.front) radiance = texture_value<F>(s, m.texture, h.u, h.v, h.p);
-        return SHADE_TERMINATE;
-    }
+// Material::scatter + the pdf handling of renderer.rs:205-227 for every material that can scatter.
+// Returns false when the ray is absorbed. On true, `ray` is the scattered ray and `thr` has been
+// multiplied by attenuation / divisor. `g` is the bounce's scatter stream.
+template <uint32_t F>
+MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevMaterial& m, const HitInfo& h, Rng& g, Ray& ray, V3& thr) {
+    uint32_t mk = m.kind;
     if ((F & F_MAT_METAL) && mk == MK_METAL) {
         // material.rs:86-100
         V3 reflected = ray.d - (2.f * dot(h.n, ray.d)) * h.n;
         V3 sd = reflected + m.param * rand_in_unit_sphere(g);
-        if (!(dot(h.n, sd) > 0.f)) return SHADE_TERMINATE;
+        if (!(dot(h.n, sd) > 0.f)) return false;
         ray.o = h.p;
-        ray.d = normalize(sd);
+        ray.d = fast_normalize(sd);
         thr = cmul(thr, v3(m.albedo));
-        return SHADE_CONTINUE;
+        return true;
     }
     if ((F & F_MAT_DIELECTRIC) && mk == MK_DIELECTRIC) {
         // material.rs:129-151
-        float ratio = h.front ? 1.f / m.param : m.param;
+        float ratio = h.front ? fast_rcp(m.param) : m.param;
         float cos_theta = fminf(-dot(ray.d, h.n), 1.f);
-        float sin_theta = sqrtf(1.f - cos_theta * cos_theta);
+        float sin_theta = fast_sqrt(1.f - cos_theta * cos_theta);
         bool reflect = ratio * sin_theta > 1.f;
         if (!reflect) {
-            float r0 = (1.f - ratio) / (1.f + ratio);
+            float r0 = (1.f - ratio) * fast_rcp(1.f + ratio);
             r0 = r0 * r0;
             float x = 1.f - cos_theta;
             float x2 = x * x;
             float refl = r0 + (1.f - r0) * (x2 * x2 * x);  // material.rs:121-125
-            reflect = refl > g.next();
+            reflect = refl > g.next();                      // drawn only when refraction is possible
         }
-        V3 dir;
-        if (reflect) {
-            dir = ray.d - (2.f * dot(h.n, ray.d)) * h.n;  // material.rs:75-77
-        } else {
-            // material.rs:114-119
-            float ct = fminf(-dot(ray.d, h.n), 1.f);
-            V3 perp = ratio * (ray.d + ct * h.n);
-            V3 par = (-sqrtf(fabsf(1.f - norm_squared(perp)))) * h.n;
-            dir = normalize(perp + par);
-        }
+        V3 perp = ratio * (ray.d + cos_theta * h.n);        // material.rs:114-119
+        V3 par = (-fast_sqrt(fabsf(1.f - norm_squared(perp)))) * h.n;
+        V3 refr = fast_normalize(perp + par);
+        V3 refl_d = ray.d - (2.f * dot(h.n, ray.d)) * h.n;  // material.rs:75-77
         ray.o = h.p;
-        ray.d = dir;
-        return SHADE_CONTINUE;  // attenuation 1, divisor 1
+        ray.d = reflect ? refl_d : refr;
+        return true;                                        // attenuation 1, divisor 1
     }
     if ((F & F_MAT_ISOTROPIC) && mk == MK_ISOTROPIC) {
         // material.rs:194-199
-        V3 dir = normalize(rand_in_unit_sphere(g));
-        V3 att = texture_value<F>(s, m.texture, h.u, h.v, h.p);
+        V3 dir = fast_normalize(rand_in_unit_sphere(g));
+        V3 att = texture_value<F>(s, tb, m.texture, h.u, h.v, h.p);
         ray.o = h.p;
         ray.d = dir;
         thr = cmul(thr, att);
-        return SHADE_CONTINUE;
+        return true;
     }
     // Lambertian — material.rs:51-61 with the mixture of renderer.rs:207-221
-    V3 att = texture_value<F>(s, m.texture, h.u, h.v, h.p);
+    V3 att = texture_value<F>(s, tb, m.texture, h.u, h.v, h.p);
     Onb uvw = onb_from_w(h.n);
     V3 dir;
     float pdf_val;
@@ -675,7 +707,7 @@ MIRT_DEV ShadeResult shade(const DevScene& s, Ray& ray, float t, int prim, const
         float a = g.next(), b = g.next();
         dir = onb_local(uvw, random_cosine_direction(a, b));       // pdf.rs:30-32
         float c = dot(dir, uvw.w);
-        pdf_val = c <= 0.f ? 0.0001f : c / kPi;                     // pdf.rs:25-28
+        pdf_val = c <= 0.f ? 0.0001f : c * (1.f / kPi);             // pdf.rs:25-28
     } else {
         float sel = g.next();
         float a = g.next(), b = g.next();
@@ -686,22 +718,26 @@ MIRT_DEV ShadeResult shade(const DevScene& s, Ray& ray, float t, int prim, const
             // ray.rs:152-154: member floor(n * xi)
             uint32_t li = (uint32_t)(0.f + ((float)s.n_lights - 0.f) * a);
             li = min(li, s.n_lights - 1);
-            dir = light_random_one<F>(s.prims[s.lights[li]], h.p, b, c);
+            dir = light_random_one<F>(tb.prims[s.lights[li]], h.p, b, c);
         }
         float c = dot(dir, uvw.w);
-        float p0 = c <= 0.f ? 0.0001f : c / kPi;
+        float p0 = c <= 0.f ? 0.0001f : c * (1.f / kPi);
         float p1 = lights_pdf<F>(s, h.p, dir);
         pdf_val = 0.5f * p0 + 0.5f * p1;                            // pdf.rs:73-75
     }
     float cosine = fmaxf(dot(dir, h.n), 0.0001f);                   // renderer.rs:219
-    float divisor = pdf_val / cosine * kPi * 2.f;                   // renderer.rs:221
+    // renderer.rs:221,227: attenuation / (pdf_val / cosine * 2 pi)
+    float w = cosine * fast_rcp(pdf_val * (2.f * kPi));
     ray.o = h.p;
     ray.d = dir;
-    thr = cmul(thr, att) / divisor;                                 // renderer.rs:227
-    return SHADE_CONTINUE;
+    thr = cmul(thr, att) * w;
+    return true;
 }
 
-// cal_norm_coords (renderer.rs:174-184) + Camera::get_ray (camera.rs:86-94)
+// cal_norm_coords (renderer.rs:174-184) + Camera::get_ray (camera.rs:86-94). When the lens radius
+// is 0 and nothing in the scene moves, the lens-disk and shutter draws cannot influence the ray
+// and are skipped (PINHOLE).
+template <bool PINHOLE>
 MIRT_DEV Ray camera_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t width, uint32_t height, bool jitter, Rng& g) {
     float xo = 0.f, yo = 0.f;
     if (jitter) {
@@ -710,11 +746,18 @@ MIRT_DEV Ray camera_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t w
     }
     float s = ((float)x + xo) / (float)(width - 1);
     float t = ((float)y + yo) / (float)(height - 1);
+    Ray r;
+    V3 target = ((v3(cam.llc) + s * v3(cam.horizontal)) + t * v3(cam.vertical)) - v3(cam.origin);
+    if (PINHOLE) {
+        r.o = v3(cam.origin);
+        r.d = fast_normalize(target);
+        r.time = cam.time0;
+        return r;
+    }
     V3 rd = cam.lens_radius * rand_in_unit_disk(g);
     V3 offset = v3(cam.u) * rd.x + v3(cam.v) * rd.y;
-    Ray r;
     r.o = v3(cam.origin) + offset;
-    r.d = normalize((((v3(cam.llc) + s * v3(cam.horizontal)) + t * v3(cam.vertical)) - v3(cam.origin)) - offset);
+    r.d = fast_normalize(target - offset);
     r.time = g.range(cam.time0, cam.time1);
     return r;
 }

@@ -111,6 +111,7 @@ struct DevScene {
     const DevBvhNode* bvh_nodes;
     const uint32_t* bvh_objects;
     uint32_t n_prims, n_entries, n_lights, n_media;
+    uint32_t n_instances, n_materials, n_textures;
     uint32_t features;
     float background[3];
 };

@@ -16,6 +16,9 @@ namespace mirt {
 
 constexpr int kBlock = 256;
 
+// capacity of the per-block LDS copies of the tables shading indexes per lane
+constexpr uint32_t kLdsPrims = 64, kLdsInstances = 16, kLdsMaterials = 32, kLdsTextures = 32;
+
 // Pixel owned by a thread: a 256-thread block covers 32x8 pixels, each wave an 8x8 tile, so the
 // lanes of a wave trace neighbouring paths.
 __device__ __forceinline__ void thread_pixel(uint32_t width, uint32_t& x, uint32_t& y) {
@@ -26,61 +29,117 @@ __device__ __forceinline__ void thread_pixel(uint32_t width, uint32_t& x, uint32
     y = by * 8u + (lane >> 3);
 }
 
-template <uint32_t F>
+template <class T>
+__device__ __forceinline__ void copy_to_lds(T* dst, const T* src, uint32_t n) {
+    const uint32_t words = n * (uint32_t)(sizeof(T) / 4);
+    uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src);
+    for (uint32_t i = threadIdx.x; i < words; i += kBlock) d[i] = s[i];
+}
+
+// F: feature mask. LDS_TABLES: primitives / instances / materials / textures are copied to LDS once
+// per block and shading reads them there. PINHOLE: lens radius 0 and nothing moves.
+template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
 __global__ __launch_bounds__(kBlock) void render_fused_kernel(RenderArgs a) {
     __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
+    __shared__ DevPrim s_prims[LDS_TABLES ? kLdsPrims : 1];
+    __shared__ DevInstance s_inst[LDS_TABLES ? kLdsInstances : 1];
+    __shared__ DevMaterial s_mats[LDS_TABLES ? kLdsMaterials : 1];
+    __shared__ DevTexture s_tex[LDS_TABLES ? kLdsTextures : 1];
     uint32_t* stack = bvh_stack + threadIdx.x;
+
+    Tables tb;
+    if (LDS_TABLES) {
+        copy_to_lds(s_prims, a.scene.prims, a.scene.n_prims);
+        copy_to_lds(s_inst, a.scene.instances, a.scene.n_instances);
+        copy_to_lds(s_mats, a.scene.materials, a.scene.n_materials);
+        copy_to_lds(s_tex, a.scene.textures, a.scene.n_textures);
+        __syncthreads();
+        tb = Tables{s_prims, s_inst, s_mats, s_tex};
+    } else {
+        tb = Tables{a.scene.prims, a.scene.instances, a.scene.materials, a.scene.textures};
+    }
 
     uint32_t x, y;
     thread_pixel(a.width, x, y);
     const bool valid = x < a.width && y < a.height;
     const uint32_t pixel = y * a.width + x;
+    const bool jitter = a.jitter != 0;
 
     V3 acc = v3(0.f, 0.f, 0.f);
     uint32_t segments = 0;
-    if (valid && a.max_depth > 0) {
-        uint32_t sample = a.spp_begin;
-        const uint32_t sample_end = a.spp_begin + a.spp_count;
-        uint32_t depth_left = 0, bounce = 0;
-        Ray ray;
-        V3 thr = v3(1.f, 1.f, 1.f);
-        while (sample < sample_end) {
-            if (depth_left == 0) {
-                Rng g;
-                g.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
-                ray = camera_ray(a.cam, x, y, a.width, a.height, a.jitter != 0, g);
-                thr = v3(1.f, 1.f, 1.f);
-                depth_left = a.max_depth;
-                bounce = 0;
+    uint32_t sample = a.spp_begin;
+    const uint32_t sample_end = a.spp_begin + a.spp_count;
+    bool alive = valid && a.max_depth > 0 && sample < sample_end;
+    uint32_t depth_left = a.max_depth, bounce = 0;
+    Ray ray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f), 0.f};
+    V3 thr = v3(1.f, 1.f, 1.f);
+    if (alive) {
+        Rng g;
+        g.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
+        ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, g);
+    }
+    while (alive) {
+        // ---- trace: scene.world.hit (renderer.rs:201)
+        DrawKey key{pixel, sample, bounce, a.seed};
+        float t;
+        int prim;
+        world_hit<F>(a.scene, ray, key, stack, kBlock, t, prim);
+        ++segments;
+
+        // ---- classify; paths that end here without drawing (miss, emitter) are closed first
+        HitInfo h;
+        DevMaterial m;
+        bool ended = false;
+        V3 e = v3(0.f, 0.f, 0.f);
+        if (prim < 0) {
+            e = cmul(thr, v3(a.scene.background));  // renderer.rs:233-235
+            ended = true;
+        } else {
+            h = finalize_hit<F>(tb, ray, t, prim);
+            m = tb.materials[h.material];
+            if ((F & F_MAT_LIGHT) && m.kind == MK_DIFFUSE_LIGHT) {
+                e = cmul(thr, emitted_radiance<F>(a.scene, tb, m, h));
+                ended = true;
             }
-            DrawKey key{pixel, sample, bounce, a.seed};
-            float t;
-            int prim;
-            world_hit<F>(a.scene, ray, key, stack, kBlock, t, prim);
-            ++segments;
-            bool done;
-            V3 e;
-            if (prim < 0) {
-                e = cmul(thr, v3(a.scene.background));  // renderer.rs:233-235
-                done = true;
-            } else {
-                V3 rad;
-                ShadeResult sr = shade<F>(a.scene, ray, t, prim, key, thr, rad);
-                if (sr == SHADE_TERMINATE) {
-                    e = cmul(thr, rad);
-                    done = true;
-                } else {
-                    --depth_left;
-                    ++bounce;
-                    done = depth_left == 0;  // renderer.rs:198-200: the next level returns 0
-                    e = v3(0.f, 0.f, 0.f);
-                }
-            }
-            if (done) {
-                acc = acc + v3(sanitize(e.x), sanitize(e.y), sanitize(e.z));  // renderer.rs:107-109
+        }
+        if (ended) {
+            acc = acc + v3(sanitize(e.x), sanitize(e.y), sanitize(e.z));  // renderer.rs:107-109
+            ++sample;
+            alive = sample < sample_end;
+        }
+        // ---- one Philox block per lane and iteration serves whichever branch the lane takes next:
+        //      the camera stream of its next sample, or the scatter stream of this bounce
+        const uint32_t r_bounce = ended ? 0u : bounce;
+        const uint32_t r_stream = ended ? (uint32_t)STREAM_CAMERA : (uint32_t)STREAM_SCATTER;
+        uint32_t w0, w1, w2, w3;
+        philox4x32_10(pixel, sample, 0u, r_bounce, r_stream, a.seed, w0, w1, w2, w3);
+        Rng g;
+        g.init_with_block0(pixel, sample, r_bounce, r_stream, a.seed, w0, w1, w2, w3);
+
+        bool restart = false;  // path closed after its scatter draws: needs a camera ray from a fresh stream
+        if (!ended) {
+            bool cont = scatter<F>(a.scene, tb, m, h, g, ray, thr);
+            --depth_left;
+            ++bounce;
+            if (!cont || depth_left == 0) {  // absorbed, or renderer.rs:198-200: the next level returns 0
                 ++sample;
-                depth_left = 0;
+                alive = sample < sample_end;
+                restart = alive;
             }
+        } else if (alive) {
+            ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, g);
+            thr = v3(1.f, 1.f, 1.f);
+            depth_left = a.max_depth;
+            bounce = 0;
+        }
+        if (restart) {
+            Rng gc;
+            gc.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
+            ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, gc);
+            thr = v3(1.f, 1.f, 1.f);
+            depth_left = a.max_depth;
+            bounce = 0;
         }
     }
     if (valid) {
@@ -99,6 +158,7 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
     uint32_t* stack = bvh_stack + threadIdx.x;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
+    const Tables tb{a.scene.prims, a.scene.instances, a.scene.materials, a.scene.textures};
     const float* q = a.rays + (size_t)i * 7;
     Ray ray{v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
     DrawKey key{i, 0u, 0u, a.seed};
@@ -111,11 +171,11 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
         float* o = a.aov + (size_t)i * 12;
         for (int k = 0; k < 12; ++k) o[k] = 0.f;
         if (prim >= 0) {
-            HitInfo h = finalize_hit<F>(a.scene, ray, t, prim);
+            HitInfo h = finalize_hit<F>(tb, ray, t, prim);
             const DevMaterial& m = a.scene.materials[h.material];
             V3 c = v3(1.f, 1.f, 1.f);
             if (m.kind == MK_METAL) c = v3(m.albedo);
-            else if (m.kind != MK_DIELECTRIC) c = texture_value<F>(a.scene, m.texture, h.u, h.v, h.p);
+            else if (m.kind != MK_DIELECTRIC) c = texture_value<F>(a.scene, tb, m.texture, h.u, h.v, h.p);
             o[0] = h.p.x; o[1] = h.p.y; o[2] = h.p.z;
             o[3] = h.n.x; o[4] = h.n.y; o[5] = h.n.z;
             o[6] = h.front ? 1.f : 0.f; o[7] = h.u; o[8] = h.v;
@@ -130,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void ray_color_kernel(RayBatchArgs a) {
     uint32_t* stack = bvh_stack + threadIdx.x;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
+    const Tables tb{a.scene.prims, a.scene.instances, a.scene.materials, a.scene.textures};
     const float* q = a.rays + (size_t)i * 7;
     Ray ray{v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
     V3 thr = v3(1.f, 1.f, 1.f);
@@ -143,11 +204,15 @@ __global__ __launch_bounds__(kBlock) void ray_color_kernel(RayBatchArgs a) {
             e = cmul(thr, v3(a.scene.background));
             break;
         }
-        V3 rad;
-        if (shade<F>(a.scene, ray, t, prim, key, thr, rad) == SHADE_TERMINATE) {
-            e = cmul(thr, rad);
+        HitInfo h = finalize_hit<F>(tb, ray, t, prim);
+        DevMaterial m = tb.materials[h.material];
+        if ((F & F_MAT_LIGHT) && m.kind == MK_DIFFUSE_LIGHT) {
+            e = cmul(thr, emitted_radiance<F>(a.scene, tb, m, h));
             break;
         }
+        Rng g;
+        g.init(i, a.sample, bounce, STREAM_SCATTER, a.seed);
+        if (!scatter<F>(a.scene, tb, m, h, g, ray, thr)) break;
     }
     a.color[(size_t)i * 3 + 0] = e.x;
     a.color[(size_t)i * 3 + 1] = e.y;
@@ -194,8 +259,16 @@ static hipError_t dispatch(uint32_t features, const Args& a, hipStream_t stream)
 template <uint32_t F>
 struct RenderLauncher {
     static hipError_t run(const RenderArgs& a, hipStream_t stream) {
-        uint32_t tiles = ((a.width + 31u) / 32u) * ((a.height + 7u) / 8u);
-        hipLaunchKernelGGL(render_fused_kernel<F>, dim3(tiles), dim3(kBlock), 0, stream, a);
+        const uint32_t tiles = ((a.width + 31u) / 32u) * ((a.height + 7u) / 8u);
+        const DevScene& s = a.scene;
+        const bool lds = s.n_prims <= kLdsPrims && s.n_instances <= kLdsInstances && s.n_materials <= kLdsMaterials &&
+                         s.n_textures <= kLdsTextures;
+        const bool pinhole = a.cam.lens_radius == 0.f && !(s.features & F_MOVING);
+        dim3 grid(tiles), block(kBlock);
+        if (lds && pinhole) hipLaunchKernelGGL((render_fused_kernel<F, true, true>), grid, block, 0, stream, a);
+        else if (lds) hipLaunchKernelGGL((render_fused_kernel<F, true, false>), grid, block, 0, stream, a);
+        else if (pinhole) hipLaunchKernelGGL((render_fused_kernel<F, false, true>), grid, block, 0, stream, a);
+        else hipLaunchKernelGGL((render_fused_kernel<F, false, false>), grid, block, 0, stream, a);
         return hipGetLastError();
     }
 };

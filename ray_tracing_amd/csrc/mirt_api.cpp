@@ -398,6 +398,9 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     s.n_entries = d->n_world;
     s.n_lights = d->n_lights;
     s.n_media = n_media;
+    s.n_instances = (uint32_t)insts.size();
+    s.n_materials = d->n_materials;
+    s.n_textures = d->n_textures;
     s.features = features;
     for (int a = 0; a < 3; ++a) s.background[a] = d->background[a];
     c->scene = s;
