@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmirt.so")
+LIB_PATH = os.environ.get("MIRT_LIB", os.path.join(_HERE, "libmirt.so"))  # MIRT_LIB: A/B builds of the library
 ASSETS = os.path.join(_HERE, "assets")
 
 MIRT_OK = 0

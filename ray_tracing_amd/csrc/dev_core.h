@@ -245,10 +245,30 @@ MIRT_DEV void axis_indexes(uint32_t axis, uint32_t& xi, uint32_t& yi, uint32_t& 
 }
 
 // geo.rs:196-204 — zero-thickness plane, inclusive range and extent tests. Written in accepting
-// form so that a NaN t (direction parallel to the plane) is a miss.
+// form so that a NaN t (direction parallel to the plane) is a miss. XI, YI, ZI = geo.rs:160-166.
+template <uint32_t XI, uint32_t YI, uint32_t ZI>
+MIRT_DEV bool rect_hit_axis(const DevPrim& p, const LRay& l, float t_min, float t_max, float& t_out) {
+    float k = p.a[0];
+    float t = div_nr(k - comp(l.r.o, ZI), comp(l.r.d, ZI), comp(l.rinv, ZI));
+    float x = comp(l.r.o, XI) + t * comp(l.r.d, XI);
+    float y = comp(l.r.o, YI) + t * comp(l.r.d, YI);
+    bool h = (t >= t_min) & (t <= t_max) & (x >= p.a[1]) & (x <= p.a[2]) & (y >= p.a[3]) & (y <= p.b[0]);
+    t_out = t;
+    return h;
+}
+
+// UNIFORM: the primitive record is the same for every lane (list scans), so the axis is chosen by a
+// scalar branch; otherwise (BVH leaves) by per-lane selects.
+template <bool UNIFORM>
 MIRT_DEV bool rect_hit(const DevPrim& p, const LRay& l, float t_min, float t_max, float& t_out) {
+    uint32_t axis = (p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT;
+    if (UNIFORM) {
+        if (axis == 0) return rect_hit_axis<0, 1, 2>(p, l, t_min, t_max, t_out);
+        if (axis == 1) return rect_hit_axis<0, 2, 1>(p, l, t_min, t_max, t_out);
+        return rect_hit_axis<1, 2, 0>(p, l, t_min, t_max, t_out);
+    }
     uint32_t xi, yi, zi;
-    axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
+    axis_indexes(axis, xi, yi, zi);
     float k = p.a[0];
     float t = div_nr(k - comp(l.r.o, zi), comp(l.r.d, zi), comp(l.rinv, zi));
     float x = comp(l.r.o, xi) + t * comp(l.r.d, xi);
@@ -258,12 +278,12 @@ MIRT_DEV bool rect_hit(const DevPrim& p, const LRay& l, float t_min, float t_max
     return h;
 }
 
-template <uint32_t F>
+template <uint32_t F, bool UNIFORM>
 MIRT_DEV bool leaf_hit(const DevPrim& p, const LRay& l, float t_min, float t_max, float& t_out) {
     uint32_t kind = p.meta & PM_KIND_MASK;
     if ((F & F_SPHERE) && (!(F & F_RECT) || kind == PK_SPHERE))
         return sphere_hit_c(sphere_center<F>(p, l.r.time), p.a[3], l.r, t_min, t_max, t_out);
-    if ((F & F_RECT) && kind == PK_RECT) return rect_hit(p, l, t_min, t_max, t_out);
+    if ((F & F_RECT) && kind == PK_RECT) return rect_hit<UNIFORM>(p, l, t_min, t_max, t_out);
     return false;
 }
 
@@ -276,38 +296,72 @@ template <uint32_t F>
 MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, float t_min, float t_max, const DrawKey& key,
                          float& t_out);
 
-// HittableList::hit (ray.rs:123-133) over prims [first, first+count) whose indices are
-// wave-uniform: `t <= closest` accepts, so the later primitive wins a tie. The primitive record
-// of the next iteration is fetched (scalar loads) while the current one is tested.
+// One run of rects on one axis: a tight loop with the next record's scalar loads in flight while
+// the current one is tested. The primitive array is padded by one record, so the read past the
+// end of the last run is valid.
+template <uint32_t XI, uint32_t YI, uint32_t ZI>
+MIRT_DEV void scan_rect_run(const DevPrim* prims, uint32_t first, uint32_t count, const LRay& l, float t_min, float& closest,
+                            int& best) {
+    const DevPrim* p = prims + first;
+    float k = p->a[0], lo0 = p->a[1], hi0 = p->a[2], lo1 = p->a[3], hi1 = p->b[0];
+    const float oz = comp(l.r.o, ZI), dz = comp(l.r.d, ZI), rz = comp(l.rinv, ZI);
+    const float ox = comp(l.r.o, XI), dx = comp(l.r.d, XI), oy = comp(l.r.o, YI), dy = comp(l.r.d, YI);
+    for (uint32_t j = 0; j < count; ++j) {
+        ++p;
+        const float nk = p->a[0], nlo0 = p->a[1], nhi0 = p->a[2], nlo1 = p->a[3], nhi1 = p->b[0];
+        // geo.rs:198-204
+        float t = div_nr(k - oz, dz, rz);
+        float x = ox + t * dx;
+        float y = oy + t * dy;
+        bool h = (t >= t_min) & (t <= closest) & (x >= lo0) & (x <= hi0) & (y >= lo1) & (y <= hi1);
+        closest = h ? t : closest;
+        best = h ? (int)(first + j) : best;
+        k = nk; lo0 = nlo0; hi0 = nhi0; lo1 = nlo1; hi1 = nhi1;
+    }
+}
+
+template <uint32_t F>
+MIRT_DEV void scan_sphere_run(const DevPrim* prims, uint32_t first, uint32_t count, const LRay& l, float t_min, float& closest,
+                              int& best) {
+    for (uint32_t j = 0; j < count; ++j) {
+        const DevPrim& p = prims[first + j];
+        float t;
+        if (sphere_hit_c(sphere_center<F>(p, l.r.time), p.a[3], l.r, t_min, closest, t)) {
+            closest = t;
+            best = (int)(first + j);
+        }
+    }
+}
+
+// HittableList::hit (ray.rs:123-133) over the runs [run_first, run_first + run_count) of a list:
+// primitives are visited in list order and `t <= closest` accepts, so the later primitive wins a
+// tie. Everything indexed here is wave-uniform (scalar loads, scalar branches).
 template <uint32_t F, bool ALLOW_MEDIUM>
-MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const Ray& r, float t_min, const DrawKey& key,
-                        float& closest, int& best) {
-    if (count == 0) return;
+MIRT_DEV void run_scan(const DevScene& s, uint32_t run_first, uint32_t run_count, const Ray& r, float t_min, const DrawKey& key,
+                       float& closest, int& best) {
     uint32_t cur_inst = 0;
     LRay lr = make_lray(r);
-    const uint32_t last = first + count - 1;
-    DevPrim p = s.prims[first];
-    for (uint32_t i = first; i <= last; ++i) {
-        DevPrim nxt = s.prims[i < last ? i + 1 : last];
-        float t;
-        bool h;
-        if (ALLOW_MEDIUM && (F & F_MEDIUM) && (p.meta & PM_KIND_MASK) == PK_MEDIUM) {
-            h = medium_hit<F>(s, p, r, t_min, closest, key, t);
-        } else {
-            if (F & F_INSTANCE) {
-                uint32_t inst = p.instance;
-                if (inst != cur_inst) {
-                    cur_inst = inst;
-                    lr = make_lray(inst ? to_local(s.instances[inst], r) : r);
+    for (uint32_t q = run_first; q < run_first + run_count; ++q) {
+        const DevRun run = s.runs[q];
+        if (F & F_INSTANCE) {
+            if (run.instance != cur_inst) {
+                cur_inst = run.instance;
+                lr = make_lray(cur_inst ? to_local(s.instances[cur_inst], r) : r);
+            }
+        }
+        if ((F & F_RECT) && run.code == RUN_RECT_XY) scan_rect_run<0, 1, 2>(s.prims, run.first, run.count, lr, t_min, closest, best);
+        else if ((F & F_RECT) && run.code == RUN_RECT_XZ) scan_rect_run<0, 2, 1>(s.prims, run.first, run.count, lr, t_min, closest, best);
+        else if ((F & F_RECT) && run.code == RUN_RECT_YZ) scan_rect_run<1, 2, 0>(s.prims, run.first, run.count, lr, t_min, closest, best);
+        else if ((F & F_SPHERE) && run.code == RUN_SPHERE) scan_sphere_run<F>(s.prims, run.first, run.count, lr, t_min, closest, best);
+        else if (ALLOW_MEDIUM && (F & F_MEDIUM) && run.code == RUN_MEDIUM) {
+            for (uint32_t j = 0; j < run.count; ++j) {
+                float t;
+                if (medium_hit<F>(s, s.prims[run.first + j], r, t_min, closest, key, t)) {
+                    closest = t;
+                    best = (int)(run.first + j);
                 }
             }
-            h = leaf_hit<F>(p, lr, t_min, closest, t);
         }
-        if (h) {
-            closest = t;
-            best = (int)i;
-        }
-        p = nxt;
     }
 }
 
@@ -318,10 +372,10 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
     uint32_t bfirst = __float_as_uint(p.a[0]), bcount = __float_as_uint(p.a[1]);
     float t1 = MIRT_INF, t2 = MIRT_INF;
     int b = -1;
-    list_scan<F, false>(s, bfirst, bcount, r, -MIRT_INF, key, t1, b);
+    run_scan<F, false>(s, bfirst, bcount, r, -MIRT_INF, key, t1, b);
     if (b < 0) return false;
     b = -1;
-    list_scan<F, false>(s, bfirst, bcount, r, t1 + 0.0001f, key, t2, b);
+    run_scan<F, false>(s, bfirst, bcount, r, t1 + 0.0001f, key, t2, b);
     if (b < 0) return false;
     t1 = fmaxf(fmaxf(t_min, t1), 0.f);
     t2 = fminf(t_max, t2);
@@ -359,7 +413,7 @@ MIRT_DEV void bvh_leaf(const DevScene& s, const DevEntry& en, uint32_t slot, uin
         for (uint32_t q = 0; q < en.prims_per_object; ++q) {
             const DevPrim& p = s.prims[first + q];
             float t;
-            if (leaf_hit<F>(p, lr, t_min, closest, t)) {
+            if (leaf_hit<F, false>(p, lr, t_min, closest, t)) {
                 closest = t;
                 best = (int)(first + q);
             }
@@ -416,7 +470,7 @@ MIRT_DEV void world_hit(const DevScene& s, const Ray& r, const DrawKey& key, uin
         if ((F & F_BVH) && en.kind == EK_BVH)
             bvh_traverse<F>(s, en, r, 0.001f, closest, best, stack, stride);
         else
-            list_scan<F, true>(s, en.first_prim, en.prim_count, r, 0.001f, key, closest, best);
+            run_scan<F, true>(s, en.run_first, en.run_count, r, 0.001f, key, closest, best);
     }
     t_out = closest;
     prim_out = best;

@@ -19,7 +19,7 @@ enum : uint32_t {
 struct __attribute__((aligned(16))) DevPrim {
     // sphere: a = (center0.xyz, radius)        b = (center1.xyz, time0)     c0 = time1
     // rect:   a = (k, lo0, hi0, lo1)           b = (hi1, k_mid, 0, 0)
-    // medium: a = (bits boundary_first, bits boundary_count, neg_inv_density, bits medium_index)
+    // medium: a = (bits first boundary run, bits boundary run count, neg_inv_density, bits medium_index)
     float a[4];
     float b[4];
     float c0;
@@ -64,7 +64,19 @@ struct __attribute__((aligned(16))) DevEntry {
     uint32_t prims_per_object;
     uint32_t instance;
     uint32_t bvh_root;   // index of the root node in bvh_nodes
-    uint32_t pad0, pad1;
+    uint32_t run_first;  // EK_LIST: the entry's runs
+    uint32_t run_count;
+};
+
+// A run: consecutive primitives of a list that share kind, rect axis and instance. A list scan
+// walks runs; inside a run one specialised loop tests `count` primitives starting at `first`
+// (the order of the list, and with it the winner of equal-t hits, is unchanged).
+enum : uint32_t { RUN_SPHERE = 0, RUN_RECT_XY = 1, RUN_RECT_XZ = 2, RUN_RECT_YZ = 3, RUN_MEDIUM = 4 };
+struct __attribute__((aligned(16))) DevRun {
+    uint32_t code;
+    uint32_t instance;
+    uint32_t first;
+    uint32_t count;
 };
 
 // 64-byte node holding the boxes of both children, so one interior step is one 64-byte fetch.
@@ -110,6 +122,7 @@ struct DevScene {
     const DevInstance* instances;
     const DevBvhNode* bvh_nodes;
     const uint32_t* bvh_objects;
+    const DevRun* runs;
     uint32_t n_prims, n_entries, n_lights, n_media;
     uint32_t n_instances, n_materials, n_textures;
     uint32_t features;

@@ -15,6 +15,9 @@
 namespace mirt {
 
 constexpr int kBlock = 256;
+#ifndef MIRT_WAVES
+#define MIRT_WAVES 4
+#endif
 
 // capacity of the per-block LDS copies of the tables shading indexes per lane
 constexpr uint32_t kLdsPrims = 64, kLdsInstances = 16, kLdsMaterials = 32, kLdsTextures = 32;
@@ -40,7 +43,7 @@ __device__ __forceinline__ void copy_to_lds(T* dst, const T* src, uint32_t n) {
 // F: feature mask. LDS_TABLES: primitives / instances / materials / textures are copied to LDS once
 // per block and shading reads them there. PINHOLE: lens radius 0 and nothing moves.
 template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
-__global__ __launch_bounds__(kBlock) void render_fused_kernel(RenderArgs a) {
+__global__ __launch_bounds__(kBlock, MIRT_WAVES) void render_fused_kernel(RenderArgs a) {
     __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
     __shared__ DevPrim s_prims[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevInstance s_inst[LDS_TABLES ? kLdsInstances : 1];

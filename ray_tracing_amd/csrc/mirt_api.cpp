@@ -231,6 +231,30 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
         if (p.flags & MIRT_PRIM_FLIP_FACE) q.meta |= PM_FLIP;
         prims[i] = q;
     }
+    // ---- runs: consecutive primitives with the same kind / axis / instance (list scans walk runs)
+    std::vector<DevRun> runs;
+    auto make_runs = [&](uint32_t first, uint32_t count, uint32_t* run_first, uint32_t* run_count) {
+        *run_first = (uint32_t)runs.size();
+        for (uint32_t i = first; i < first + count; ++i) {
+            const mirt_prim& p = d->prims[i];
+            uint32_t code = p.kind == MIRT_PRIM_SPHERE ? RUN_SPHERE : (p.kind == MIRT_PRIM_MEDIUM ? RUN_MEDIUM : RUN_RECT_XY + p.axis);
+            if ((uint32_t)runs.size() > *run_first && runs.back().code == code && runs.back().instance == p.instance &&
+                runs.back().first + runs.back().count == i) {
+                ++runs.back().count;
+            } else {
+                runs.push_back(DevRun{code, p.instance, i, 1});
+            }
+        }
+        *run_count = (uint32_t)runs.size() - *run_first;
+    };
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const mirt_prim& p = d->prims[i];
+        if (p.kind != MIRT_PRIM_MEDIUM) continue;
+        uint32_t rf, rc;
+        make_runs(p.boundary_first, p.boundary_count, &rf, &rc);
+        std::memcpy(&prims[i].a[0], &rf, 4);
+        std::memcpy(&prims[i].a[1], &rc, 4);
+    }
     // ---- materials / textures
     std::vector<DevMaterial> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
@@ -332,6 +356,7 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
         }
         if (kind == MIRT_ENTRY_LIST) {
             q.kind = EK_LIST;
+            make_runs(w.first_prim, w.prim_count, &q.run_first, &q.run_count);
         } else if (kind == MIRT_ENTRY_BVH) {
             if (w.prim_count == 0) return bad("entry " + std::to_string(e) + ": empty BVH (aabb.rs:98)");
             if (w.prim_count % q.prims_per_object) return bad("entry " + std::to_string(e) + ": prim_count is not a multiple of prims_per_object");
@@ -384,7 +409,9 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     }
     DevScene s{};
     int rc;
+    prims.push_back(DevPrim{});  // the list scan reads one record ahead
     if ((rc = upload(c, prims, &s.prims))) return rc;
+    if ((rc = upload(c, runs, &s.runs))) return rc;
     if ((rc = upload(c, entries, &s.entries))) return rc;
     if ((rc = upload(c, lights, &s.lights))) return rc;
     if ((rc = upload(c, mats, &s.materials))) return rc;
