@@ -199,9 +199,9 @@ MIRT_DEV Ray to_local(const DevInstance& in, const Ray& r) {
 // global arrays or at the block's LDS copies (small scenes).
 struct Tables {
     const DevPrim* prims;
+    const DevShade* shade;
     const DevInstance* instances;
-    const DevMaterial* materials;
-    const DevTexture* textures;
+    const DevPrim* light_prims;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -296,72 +296,54 @@ template <uint32_t F>
 MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, float t_min, float t_max, const DrawKey& key,
                          float& t_out);
 
-// One run of rects on one axis: a tight loop with the next record's scalar loads in flight while
-// the current one is tested. The primitive array is padded by one record, so the read past the
-// end of the last run is valid.
+// geo.rs:198-204 on one scan record (f = k, lo0, hi0, lo1, hi1), written in accepting form so that a
+// NaN t (direction parallel to the plane) is a miss. XI, YI, ZI = geo.rs:160-166.
 template <uint32_t XI, uint32_t YI, uint32_t ZI>
-MIRT_DEV void scan_rect_run(const DevPrim* prims, uint32_t first, uint32_t count, const LRay& l, float t_min, float& closest,
-                            int& best) {
-    const DevPrim* p = prims + first;
-    float k = p->a[0], lo0 = p->a[1], hi0 = p->a[2], lo1 = p->a[3], hi1 = p->b[0];
-    const float oz = comp(l.r.o, ZI), dz = comp(l.r.d, ZI), rz = comp(l.rinv, ZI);
-    const float ox = comp(l.r.o, XI), dx = comp(l.r.d, XI), oy = comp(l.r.o, YI), dy = comp(l.r.d, YI);
-    for (uint32_t j = 0; j < count; ++j) {
-        ++p;
-        const float nk = p->a[0], nlo0 = p->a[1], nhi0 = p->a[2], nlo1 = p->a[3], nhi1 = p->b[0];
-        // geo.rs:198-204
-        float t = div_nr(k - oz, dz, rz);
-        float x = ox + t * dx;
-        float y = oy + t * dy;
-        bool h = (t >= t_min) & (t <= closest) & (x >= lo0) & (x <= hi0) & (y >= lo1) & (y <= hi1);
-        closest = h ? t : closest;
-        best = h ? (int)(first + j) : best;
-        k = nk; lo0 = nlo0; hi0 = nhi0; lo1 = nlo1; hi1 = nhi1;
-    }
+MIRT_DEV bool rect_rec_hit(const float* f, const LRay& l, float t_min, float t_max, float& t_out) {
+    float t = div_nr(f[0] - comp(l.r.o, ZI), comp(l.r.d, ZI), comp(l.rinv, ZI));
+    float x = comp(l.r.o, XI) + t * comp(l.r.d, XI);
+    float y = comp(l.r.o, YI) + t * comp(l.r.d, YI);
+    t_out = t;
+    return (t >= t_min) & (t <= t_max) & (x >= f[1]) & (x <= f[2]) & (y >= f[3]) & (y <= f[4]);
 }
 
-template <uint32_t F>
-MIRT_DEV void scan_sphere_run(const DevPrim* prims, uint32_t first, uint32_t count, const LRay& l, float t_min, float& closest,
-                              int& best) {
-    for (uint32_t j = 0; j < count; ++j) {
-        const DevPrim& p = prims[first + j];
-        float t;
-        if (sphere_hit_c(sphere_center<F>(p, l.r.time), p.a[3], l.r, t_min, closest, t)) {
-            closest = t;
-            best = (int)(first + j);
-        }
-    }
-}
-
-// HittableList::hit (ray.rs:123-133) over the runs [run_first, run_first + run_count) of a list:
+// HittableList::hit (ray.rs:123-133) over the scan records [first, first + count) of a list:
 // primitives are visited in list order and `t <= closest` accepts, so the later primitive wins a
-// tie. Everything indexed here is wave-uniform (scalar loads, scalar branches).
+// tie. Records are wave-uniform: one 32-byte scalar load each, issued one record ahead of its use,
+// and the kind / axis dispatch is a scalar branch.
 template <uint32_t F, bool ALLOW_MEDIUM>
-MIRT_DEV void run_scan(const DevScene& s, uint32_t run_first, uint32_t run_count, const Ray& r, float t_min, const DrawKey& key,
-                       float& closest, int& best) {
+MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const Ray& r, float t_min, const DrawKey& key,
+                        float& closest, int& best) {
     uint32_t cur_inst = 0;
     LRay lr = make_lray(r);
-    for (uint32_t q = run_first; q < run_first + run_count; ++q) {
-        const DevRun run = s.runs[q];
+    const DevScanRec* p = s.scan + first;
+    DevScanRec rec = *p;
+    for (uint32_t j = 0; j < count; ++j) {
+        ++p;
+        const DevScanRec nxt = *p;  // the array ends with an SC_END record
+        const uint32_t code = rec.code_inst & 0xffu;
         if (F & F_INSTANCE) {
-            if (run.instance != cur_inst) {
-                cur_inst = run.instance;
-                lr = make_lray(cur_inst ? to_local(s.instances[cur_inst], r) : r);
+            const uint32_t inst = rec.code_inst >> 8;
+            if (inst != cur_inst) {
+                cur_inst = inst;
+                lr = make_lray(inst ? to_local(s.instances[inst], r) : r);
             }
         }
-        if ((F & F_RECT) && run.code == RUN_RECT_XY) scan_rect_run<0, 1, 2>(s.prims, run.first, run.count, lr, t_min, closest, best);
-        else if ((F & F_RECT) && run.code == RUN_RECT_XZ) scan_rect_run<0, 2, 1>(s.prims, run.first, run.count, lr, t_min, closest, best);
-        else if ((F & F_RECT) && run.code == RUN_RECT_YZ) scan_rect_run<1, 2, 0>(s.prims, run.first, run.count, lr, t_min, closest, best);
-        else if ((F & F_SPHERE) && run.code == RUN_SPHERE) scan_sphere_run<F>(s.prims, run.first, run.count, lr, t_min, closest, best);
-        else if (ALLOW_MEDIUM && (F & F_MEDIUM) && run.code == RUN_MEDIUM) {
-            for (uint32_t j = 0; j < run.count; ++j) {
-                float t;
-                if (medium_hit<F>(s, s.prims[run.first + j], r, t_min, closest, key, t)) {
-                    closest = t;
-                    best = (int)(run.first + j);
-                }
-            }
+        float t = 0.f;
+        bool h = false;
+        if ((F & F_RECT) && code == SC_RECT_XY) h = rect_rec_hit<0, 1, 2>(rec.f, lr, t_min, closest, t);
+        else if ((F & F_RECT) && code == SC_RECT_XZ) h = rect_rec_hit<0, 2, 1>(rec.f, lr, t_min, closest, t);
+        else if ((F & F_RECT) && code == SC_RECT_YZ) h = rect_rec_hit<1, 2, 0>(rec.f, lr, t_min, closest, t);
+        else if ((F & F_SPHERE) && code == SC_SPHERE) h = sphere_hit_c(v3(rec.f), rec.f[3], lr.r, t_min, closest, t);
+        else if ((F & F_MOVING) && code == SC_SPHERE_MOVING) {
+            const DevPrim& q = s.prims[rec.prim];
+            h = sphere_hit_c(sphere_center<F>(q, lr.r.time), q.a[3], lr.r, t_min, closest, t);
+        } else if (ALLOW_MEDIUM && (F & F_MEDIUM) && code == SC_MEDIUM) {
+            h = medium_hit<F>(s, s.prims[rec.prim], r, t_min, closest, key, t);
         }
+        closest = h ? t : closest;
+        best = h ? (int)rec.prim : best;
+        rec = nxt;
     }
 }
 
@@ -372,10 +354,10 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
     uint32_t bfirst = __float_as_uint(p.a[0]), bcount = __float_as_uint(p.a[1]);
     float t1 = MIRT_INF, t2 = MIRT_INF;
     int b = -1;
-    run_scan<F, false>(s, bfirst, bcount, r, -MIRT_INF, key, t1, b);
+    list_scan<F, false>(s, bfirst, bcount, r, -MIRT_INF, key, t1, b);
     if (b < 0) return false;
     b = -1;
-    run_scan<F, false>(s, bfirst, bcount, r, t1 + 0.0001f, key, t2, b);
+    list_scan<F, false>(s, bfirst, bcount, r, t1 + 0.0001f, key, t2, b);
     if (b < 0) return false;
     t1 = fmaxf(fmaxf(t_min, t1), 0.f);
     t2 = fminf(t_max, t2);
@@ -470,7 +452,7 @@ MIRT_DEV void world_hit(const DevScene& s, const Ray& r, const DrawKey& key, uin
         if ((F & F_BVH) && en.kind == EK_BVH)
             bvh_traverse<F>(s, en, r, 0.001f, closest, best, stack, stride);
         else
-            run_scan<F, true>(s, en.run_first, en.run_count, r, 0.001f, key, closest, best);
+            list_scan<F, true>(s, en.scan_first, en.scan_count, r, 0.001f, key, closest, best);
     }
     t_out = closest;
     prim_out = best;
@@ -483,14 +465,12 @@ struct HitInfo {
     V3 p, n;
     float u, v;
     bool front;
-    uint32_t material;
 };
 
 template <uint32_t F>
 MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim) {
     const DevPrim& p = tb.prims[prim];
     HitInfo h;
-    h.material = p.material;
     h.u = 0.f;
     h.v = 0.f;
     uint32_t kind = p.meta & PM_KIND_MASK;
@@ -589,8 +569,8 @@ MIRT_DEV float perlin_turb(const DevPerlin& pl, V3 p) {
 }
 
 template <uint32_t F>
-MIRT_DEV V3 texture_value(const DevScene& s, const Tables& tb, uint32_t tex, float u, float v, V3 p) {
-    const DevTexture& t = tb.textures[tex];
+MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 p) {
+    const DevTexture& t = s.textures[tex];
     uint32_t kind = t.kind;
     if ((F & F_TEX_CHECKER) && kind == TK_CHECKER) {
         // texture.rs:42-46
@@ -664,7 +644,7 @@ template <uint32_t F>
 MIRT_DEV float lights_pdf(const DevScene& s, V3 origin, V3 v) {
     V3 vinv = v3(fast_rcp(v.x), fast_rcp(v.y), fast_rcp(v.z));
     float sum = 0.f;
-    for (uint32_t i = 0; i < s.n_lights; ++i) sum += light_pdf_one<F>(s.prims[s.lights[i]], origin, v, vinv);
+    for (uint32_t i = 0; i < s.n_lights; ++i) sum += light_pdf_one<F>(s.light_prims[i], origin, v, vinv);
     return sum * fast_rcp((float)s.n_lights);
 }
 
@@ -698,10 +678,18 @@ MIRT_DEV V3 light_random_one(const DevPrim& p, V3 origin, float xi1, float xi2) 
 // ---------------------------------------------------------------------------------------------
 // one level of ray_color (renderer.rs:197-237) after world.hit found a primitive
 // ---------------------------------------------------------------------------------------------
+// Value of the material's texture at the hit (texture.rs): the colour resolved at upload when the
+// texture is a solid colour, the general evaluation otherwise.
+template <uint32_t F>
+MIRT_DEV V3 shade_color(const DevScene& s, const DevShade& m, const HitInfo& h) {
+    if ((F & (F_TEX_CHECKER | F_TEX_NOISE | F_TEX_IMAGE)) && m.tex_kind != TK_SOLID) return texture_value<F>(s, m.texture, h.u, h.v, h.p);
+    return v3(m.color);
+}
+
 // material.rs:167-175: a DiffuseLight never scatters and emits toward front_face only.
 template <uint32_t F>
-MIRT_DEV V3 emitted_radiance(const DevScene& s, const Tables& tb, const DevMaterial& m, const HitInfo& h) {
-    if (h.front) return texture_value<F>(s, tb, m.texture, h.u, h.v, h.p);
+MIRT_DEV V3 emitted_radiance(const DevScene& s, const DevShade& m, const HitInfo& h) {
+    if (h.front) return shade_color<F>(s, m, h);
     return v3(0.f, 0.f, 0.f);
 }
 
@@ -709,8 +697,8 @@ MIRT_DEV V3 emitted_radiance(const DevScene& s, const Tables& tb, const DevMater
 // Returns false when the ray is absorbed. On true, `ray` is the scattered ray and `thr` has been
 // multiplied by attenuation / divisor. `g` is the bounce's scatter stream.
 template <uint32_t F>
-MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevMaterial& m, const HitInfo& h, Rng& g, Ray& ray, V3& thr) {
-    uint32_t mk = m.kind;
+MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, const HitInfo& h, Rng& g, Ray& ray, V3& thr) {
+    uint32_t mk = m.mat_kind;
     if ((F & F_MAT_METAL) && mk == MK_METAL) {
         // material.rs:86-100
         V3 reflected = ray.d - (2.f * dot(h.n, ray.d)) * h.n;
@@ -718,7 +706,7 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevMaterial& m,
         if (!(dot(h.n, sd) > 0.f)) return false;
         ray.o = h.p;
         ray.d = fast_normalize(sd);
-        thr = cmul(thr, v3(m.albedo));
+        thr = cmul(thr, v3(m.color));
         return true;
     }
     if ((F & F_MAT_DIELECTRIC) && mk == MK_DIELECTRIC) {
@@ -746,14 +734,14 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevMaterial& m,
     if ((F & F_MAT_ISOTROPIC) && mk == MK_ISOTROPIC) {
         // material.rs:194-199
         V3 dir = fast_normalize(rand_in_unit_sphere(g));
-        V3 att = texture_value<F>(s, tb, m.texture, h.u, h.v, h.p);
+        V3 att = shade_color<F>(s, m, h);
         ray.o = h.p;
         ray.d = dir;
         thr = cmul(thr, att);
         return true;
     }
     // Lambertian — material.rs:51-61 with the mixture of renderer.rs:207-221
-    V3 att = texture_value<F>(s, tb, m.texture, h.u, h.v, h.p);
+    V3 att = shade_color<F>(s, m, h);
     Onb uvw = onb_from_w(h.n);
     V3 dir;
     float pdf_val;
@@ -772,7 +760,7 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevMaterial& m,
             // ray.rs:152-154: member floor(n * xi)
             uint32_t li = (uint32_t)(0.f + ((float)s.n_lights - 0.f) * a);
             li = min(li, s.n_lights - 1);
-            dir = light_random_one<F>(tb.prims[s.lights[li]], h.p, b, c);
+            dir = light_random_one<F>(tb.light_prims[li], h.p, b, c);
         }
         float c = dot(dir, uvw.w);
         float p0 = c <= 0.f ? 0.0001f : c * (1.f / kPi);

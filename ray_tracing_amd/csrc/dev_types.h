@@ -1,7 +1,7 @@
 // Device-resident scene layout. Built once by the upload code from the mirt_scene_desc arrays and
-// passed to every kernel by value (it lands in SGPRs / the kernarg segment). Everything a ray
-// touches per primitive is a multiple of 16 bytes so that one primitive is three dwordx4 loads —
-// scalar loads when the index is wave-uniform (list scans), vector loads in BVH leaves.
+// passed to every kernel by value (it lands in SGPRs / the kernarg segment). Records are multiples
+// of 16 bytes: list scans fetch them with scalar loads (wave-uniform index, data stays in SGPRs),
+// BVH leaves and shading fetch them with vector / LDS loads.
 #pragma once
 #include <stdint.h>
 
@@ -19,7 +19,7 @@ enum : uint32_t {
 struct __attribute__((aligned(16))) DevPrim {
     // sphere: a = (center0.xyz, radius)        b = (center1.xyz, time0)     c0 = time1
     // rect:   a = (k, lo0, hi0, lo1)           b = (hi1, k_mid, 0, 0)
-    // medium: a = (bits first boundary run, bits boundary run count, neg_inv_density, bits medium_index)
+    // medium: a = (bits first boundary scan record, bits record count, neg_inv_density, bits medium_index)
     float a[4];
     float b[4];
     float c0;
@@ -29,15 +29,33 @@ struct __attribute__((aligned(16))) DevPrim {
 };
 static_assert(sizeof(DevPrim) == 48, "DevPrim is three 16-byte quads");
 
+// One element of a list scan (32 bytes = one s_load_dwordx8). A list (world entry or the boundary of
+// a medium) is a contiguous range of these in list order; the array ends with one SC_END record so
+// that the scan may always read one record ahead.
+//   rect:   f = (k, lo0, hi0, lo1, hi1, -)      sphere: f = (center.xyz, radius, -, -)
+//   moving sphere / medium: data comes from prims[prim]
+enum : uint32_t { SC_SPHERE = 0, SC_RECT_XY = 1, SC_RECT_XZ = 2, SC_RECT_YZ = 3, SC_MEDIUM = 4, SC_SPHERE_MOVING = 5, SC_END = 6 };
+struct __attribute__((aligned(32))) DevScanRec {
+    uint32_t code_inst;  // code | instance << 8
+    uint32_t prim;       // index into prims (the id reported for a hit)
+    float f[6];
+};
+static_assert(sizeof(DevScanRec) == 32, "DevScanRec is one 32-byte scalar load");
+
+// What shading needs to know about the material of a primitive, resolved at upload so that a hit
+// costs one table read: material kind, its parameter, and — for Metal, or for a texture that is a
+// solid colour — the colour itself. Other textures are evaluated through `texture`.
+struct __attribute__((aligned(16))) DevShade {
+    uint32_t mat_kind;
+    uint32_t tex_kind;
+    uint32_t texture;
+    float param;
+    float color[4];
+};
+
 struct __attribute__((aligned(16))) DevInstance {
     float sin_t, cos_t, ox, oy;
     float oz, pad0, pad1, pad2;
-};
-
-struct __attribute__((aligned(16))) DevMaterial {
-    uint32_t kind, texture;
-    float param, pad;
-    float albedo[4];
 };
 
 struct __attribute__((aligned(16))) DevTexture {
@@ -63,20 +81,9 @@ struct __attribute__((aligned(16))) DevEntry {
     uint32_t prim_count;
     uint32_t prims_per_object;
     uint32_t instance;
-    uint32_t bvh_root;   // index of the root node in bvh_nodes
-    uint32_t run_first;  // EK_LIST: the entry's runs
-    uint32_t run_count;
-};
-
-// A run: consecutive primitives of a list that share kind, rect axis and instance. A list scan
-// walks runs; inside a run one specialised loop tests `count` primitives starting at `first`
-// (the order of the list, and with it the winner of equal-t hits, is unchanged).
-enum : uint32_t { RUN_SPHERE = 0, RUN_RECT_XY = 1, RUN_RECT_XZ = 2, RUN_RECT_YZ = 3, RUN_MEDIUM = 4 };
-struct __attribute__((aligned(16))) DevRun {
-    uint32_t code;
-    uint32_t instance;
-    uint32_t first;
-    uint32_t count;
+    uint32_t bvh_root;    // EK_BVH: index of the root node in bvh_nodes
+    uint32_t scan_first;  // EK_LIST: the entry's scan records
+    uint32_t scan_count;
 };
 
 // 64-byte node holding the boxes of both children, so one interior step is one 64-byte fetch.
@@ -112,19 +119,19 @@ enum : uint32_t {
 };
 
 struct DevScene {
-    const DevPrim* prims;
+    const DevPrim* prims;         // n_prims + 1 records
+    const DevShade* shade;        // per primitive
+    const DevScanRec* scan;       // list-scan records, SC_END terminated
     const DevEntry* entries;
-    const uint32_t* lights;
-    const DevMaterial* materials;
+    const DevPrim* light_prims;   // copies of the light primitives, in light order
     const DevTexture* textures;
     const DevImage* images;
     const DevPerlin* perlins;
     const DevInstance* instances;
     const DevBvhNode* bvh_nodes;
     const uint32_t* bvh_objects;
-    const DevRun* runs;
     uint32_t n_prims, n_entries, n_lights, n_media;
-    uint32_t n_instances, n_materials, n_textures;
+    uint32_t n_instances, n_textures;
     uint32_t features;
     float background[3];
 };

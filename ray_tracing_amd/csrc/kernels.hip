@@ -20,7 +20,7 @@ constexpr int kBlock = 256;
 #endif
 
 // capacity of the per-block LDS copies of the tables shading indexes per lane
-constexpr uint32_t kLdsPrims = 64, kLdsInstances = 16, kLdsMaterials = 32, kLdsTextures = 32;
+constexpr uint32_t kLdsPrims = 64, kLdsInstances = 16, kLdsLights = 8;
 
 // Pixel owned by a thread: a 256-thread block covers 32x8 pixels, each wave an 8x8 tile, so the
 // lanes of a wave trace neighbouring paths.
@@ -46,21 +46,21 @@ template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
 __global__ __launch_bounds__(kBlock, MIRT_WAVES) void render_fused_kernel(RenderArgs a) {
     __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
     __shared__ DevPrim s_prims[LDS_TABLES ? kLdsPrims : 1];
+    __shared__ DevShade s_shade[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevInstance s_inst[LDS_TABLES ? kLdsInstances : 1];
-    __shared__ DevMaterial s_mats[LDS_TABLES ? kLdsMaterials : 1];
-    __shared__ DevTexture s_tex[LDS_TABLES ? kLdsTextures : 1];
+    __shared__ DevPrim s_lights[LDS_TABLES ? kLdsLights : 1];
     uint32_t* stack = bvh_stack + threadIdx.x;
 
     Tables tb;
     if (LDS_TABLES) {
         copy_to_lds(s_prims, a.scene.prims, a.scene.n_prims);
+        copy_to_lds(s_shade, a.scene.shade, a.scene.n_prims);
         copy_to_lds(s_inst, a.scene.instances, a.scene.n_instances);
-        copy_to_lds(s_mats, a.scene.materials, a.scene.n_materials);
-        copy_to_lds(s_tex, a.scene.textures, a.scene.n_textures);
+        copy_to_lds(s_lights, a.scene.light_prims, a.scene.n_lights);
         __syncthreads();
-        tb = Tables{s_prims, s_inst, s_mats, s_tex};
+        tb = Tables{s_prims, s_shade, s_inst, s_lights};
     } else {
-        tb = Tables{a.scene.prims, a.scene.instances, a.scene.materials, a.scene.textures};
+        tb = Tables{a.scene.prims, a.scene.shade, a.scene.instances, a.scene.light_prims};
     }
 
     uint32_t x, y;
@@ -92,17 +92,17 @@ __global__ __launch_bounds__(kBlock, MIRT_WAVES) void render_fused_kernel(Render
 
         // ---- classify; paths that end here without drawing (miss, emitter) are closed first
         HitInfo h;
-        DevMaterial m;
+        DevShade m;
         bool ended = false;
         V3 e = v3(0.f, 0.f, 0.f);
         if (prim < 0) {
             e = cmul(thr, v3(a.scene.background));  // renderer.rs:233-235
             ended = true;
         } else {
+            m = tb.shade[prim];
             h = finalize_hit<F>(tb, ray, t, prim);
-            m = tb.materials[h.material];
-            if ((F & F_MAT_LIGHT) && m.kind == MK_DIFFUSE_LIGHT) {
-                e = cmul(thr, emitted_radiance<F>(a.scene, tb, m, h));
+            if ((F & F_MAT_LIGHT) && m.mat_kind == MK_DIFFUSE_LIGHT) {
+                e = cmul(thr, emitted_radiance<F>(a.scene, m, h));
                 ended = true;
             }
         }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
     uint32_t* stack = bvh_stack + threadIdx.x;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
-    const Tables tb{a.scene.prims, a.scene.instances, a.scene.materials, a.scene.textures};
+    const Tables tb{a.scene.prims, a.scene.shade, a.scene.instances, a.scene.light_prims};
     const float* q = a.rays + (size_t)i * 7;
     Ray ray{v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
     DrawKey key{i, 0u, 0u, a.seed};
@@ -175,10 +175,9 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
         for (int k = 0; k < 12; ++k) o[k] = 0.f;
         if (prim >= 0) {
             HitInfo h = finalize_hit<F>(tb, ray, t, prim);
-            const DevMaterial& m = a.scene.materials[h.material];
+            const DevShade m = a.scene.shade[prim];
             V3 c = v3(1.f, 1.f, 1.f);
-            if (m.kind == MK_METAL) c = v3(m.albedo);
-            else if (m.kind != MK_DIELECTRIC) c = texture_value<F>(a.scene, tb, m.texture, h.u, h.v, h.p);
+            if (m.mat_kind != MK_DIELECTRIC) c = shade_color<F>(a.scene, m, h);
             o[0] = h.p.x; o[1] = h.p.y; o[2] = h.p.z;
             o[3] = h.n.x; o[4] = h.n.y; o[5] = h.n.z;
             o[6] = h.front ? 1.f : 0.f; o[7] = h.u; o[8] = h.v;
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void ray_color_kernel(RayBatchArgs a) {
     uint32_t* stack = bvh_stack + threadIdx.x;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
-    const Tables tb{a.scene.prims, a.scene.instances, a.scene.materials, a.scene.textures};
+    const Tables tb{a.scene.prims, a.scene.shade, a.scene.instances, a.scene.light_prims};
     const float* q = a.rays + (size_t)i * 7;
     Ray ray{v3(q[0], q[1], q[2]), v3(q[3], q[4], q[5]), q[6]};
     V3 thr = v3(1.f, 1.f, 1.f);
@@ -208,9 +207,9 @@ __global__ __launch_bounds__(kBlock) void ray_color_kernel(RayBatchArgs a) {
             break;
         }
         HitInfo h = finalize_hit<F>(tb, ray, t, prim);
-        DevMaterial m = tb.materials[h.material];
-        if ((F & F_MAT_LIGHT) && m.kind == MK_DIFFUSE_LIGHT) {
-            e = cmul(thr, emitted_radiance<F>(a.scene, tb, m, h));
+        DevShade m = tb.shade[prim];
+        if ((F & F_MAT_LIGHT) && m.mat_kind == MK_DIFFUSE_LIGHT) {
+            e = cmul(thr, emitted_radiance<F>(a.scene, m, h));
             break;
         }
         Rng g;
@@ -264,8 +263,7 @@ struct RenderLauncher {
     static hipError_t run(const RenderArgs& a, hipStream_t stream) {
         const uint32_t tiles = ((a.width + 31u) / 32u) * ((a.height + 7u) / 8u);
         const DevScene& s = a.scene;
-        const bool lds = s.n_prims <= kLdsPrims && s.n_instances <= kLdsInstances && s.n_materials <= kLdsMaterials &&
-                         s.n_textures <= kLdsTextures;
+        const bool lds = s.n_prims <= kLdsPrims && s.n_instances <= kLdsInstances && s.n_lights <= kLdsLights;
         const bool pinhole = a.cam.lens_radius == 0.f && !(s.features & F_MOVING);
         dim3 grid(tiles), block(kBlock);
         if (lds && pinhole) hipLaunchKernelGGL((render_fused_kernel<F, true, true>), grid, block, 0, stream, a);

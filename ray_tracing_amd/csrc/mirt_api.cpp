@@ -231,39 +231,42 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
         if (p.flags & MIRT_PRIM_FLIP_FACE) q.meta |= PM_FLIP;
         prims[i] = q;
     }
-    // ---- runs: consecutive primitives with the same kind / axis / instance (list scans walk runs)
-    std::vector<DevRun> runs;
-    auto make_runs = [&](uint32_t first, uint32_t count, uint32_t* run_first, uint32_t* run_count) {
-        *run_first = (uint32_t)runs.size();
+    // ---- list-scan records: one 32-byte record per list member, in list order
+    std::vector<DevScanRec> scan;
+    auto make_scan = [&](uint32_t first, uint32_t count, uint32_t* scan_first, uint32_t* scan_count) {
+        *scan_first = (uint32_t)scan.size();
         for (uint32_t i = first; i < first + count; ++i) {
             const mirt_prim& p = d->prims[i];
-            uint32_t code = p.kind == MIRT_PRIM_SPHERE ? RUN_SPHERE : (p.kind == MIRT_PRIM_MEDIUM ? RUN_MEDIUM : RUN_RECT_XY + p.axis);
-            if ((uint32_t)runs.size() > *run_first && runs.back().code == code && runs.back().instance == p.instance &&
-                runs.back().first + runs.back().count == i) {
-                ++runs.back().count;
+            DevScanRec r{};
+            uint32_t code;
+            if (p.kind == MIRT_PRIM_SPHERE) {
+                code = (p.flags & MIRT_PRIM_MOVING) ? SC_SPHERE_MOVING : SC_SPHERE;
+                for (int a = 0; a < 3; ++a) r.f[a] = p.center0[a];
+                r.f[3] = p.radius;
+            } else if (p.kind == MIRT_PRIM_RECT) {
+                code = SC_RECT_XY + p.axis;
+                r.f[0] = p.k; r.f[1] = p.lo[0]; r.f[2] = p.hi[0]; r.f[3] = p.lo[1]; r.f[4] = p.hi[1];
             } else {
-                runs.push_back(DevRun{code, p.instance, i, 1});
+                code = SC_MEDIUM;
             }
+            r.code_inst = code | (p.instance << 8);
+            r.prim = i;
+            scan.push_back(r);
         }
-        *run_count = (uint32_t)runs.size() - *run_first;
+        *scan_count = (uint32_t)scan.size() - *scan_first;
     };
+    if (d->n_instances >= (1u << 24)) return bad("too many instances");
     for (uint32_t i = 0; i < d->n_prims; ++i) {
         const mirt_prim& p = d->prims[i];
         if (p.kind != MIRT_PRIM_MEDIUM) continue;
         uint32_t rf, rc;
-        make_runs(p.boundary_first, p.boundary_count, &rf, &rc);
+        make_scan(p.boundary_first, p.boundary_count, &rf, &rc);
         std::memcpy(&prims[i].a[0], &rf, 4);
         std::memcpy(&prims[i].a[1], &rc, 4);
     }
     // ---- materials / textures
-    std::vector<DevMaterial> mats(d->n_materials);
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const mirt_material& m = d->materials[i];
-        DevMaterial q{};
-        q.kind = m.kind;
-        q.texture = m.texture;
-        q.param = m.param;
-        for (int a = 0; a < 3; ++a) q.albedo[a] = m.albedo[a];
         switch (m.kind) {
             case MIRT_MAT_LAMBERTIAN: break;
             case MIRT_MAT_METAL: features |= F_MAT_METAL; break;
@@ -277,7 +280,28 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
         }
         bool textured = m.kind == MIRT_MAT_LAMBERTIAN || m.kind == MIRT_MAT_DIFFUSE_LIGHT || m.kind == MIRT_MAT_ISOTROPIC;
         if (textured && m.texture >= d->n_textures) return bad("material " + std::to_string(i) + ": texture index out of range");
-        mats[i] = q;
+    }
+    for (uint32_t i = 0; i < d->n_textures; ++i)
+        if (d->textures[i].kind > MIRT_TEX_IMAGE) return bad("texture " + std::to_string(i) + ": unknown kind");
+    // per-primitive shading record: material kind / parameter and, where it is a constant, the colour
+    std::vector<DevShade> shade(d->n_prims);
+    for (uint32_t i = 0; i < d->n_prims; ++i) {
+        const mirt_material& m = d->materials[d->prims[i].material];
+        DevShade q{};
+        q.mat_kind = m.kind;
+        q.param = m.param;
+        q.tex_kind = TK_SOLID;
+        if (m.kind == MIRT_MAT_METAL) {
+            for (int a = 0; a < 3; ++a) q.color[a] = m.albedo[a];
+        } else if (m.kind == MIRT_MAT_DIELECTRIC) {
+            for (int a = 0; a < 3; ++a) q.color[a] = 1.f;
+        } else {
+            const mirt_texture& t = d->textures[m.texture];
+            q.tex_kind = t.kind;
+            q.texture = m.texture;
+            for (int a = 0; a < 3; ++a) q.color[a] = t.color[a];
+        }
+        shade[i] = q;
     }
     std::vector<DevTexture> texs(d->n_textures);
     for (uint32_t i = 0; i < d->n_textures; ++i) {
@@ -325,6 +349,8 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
         if (d->prims[li].kind == MIRT_PRIM_MEDIUM || d->prims[li].instance)
             return bad("lights must be un-instanced spheres or rects");
     }
+    std::vector<DevPrim> light_prims;
+    for (uint32_t li : lights) light_prims.push_back(prims[li]);
     // ---- world entries + BVHs
     std::vector<DevEntry> entries(d->n_world);
     std::vector<DevBvhNode> nodes;
@@ -356,7 +382,7 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
         }
         if (kind == MIRT_ENTRY_LIST) {
             q.kind = EK_LIST;
-            make_runs(w.first_prim, w.prim_count, &q.run_first, &q.run_count);
+            make_scan(w.first_prim, w.prim_count, &q.scan_first, &q.scan_count);
         } else if (kind == MIRT_ENTRY_BVH) {
             if (w.prim_count == 0) return bad("entry " + std::to_string(e) + ": empty BVH (aabb.rs:98)");
             if (w.prim_count % q.prims_per_object) return bad("entry " + std::to_string(e) + ": prim_count is not a multiple of prims_per_object");
@@ -411,10 +437,15 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     int rc;
     prims.push_back(DevPrim{});  // the list scan reads one record ahead
     if ((rc = upload(c, prims, &s.prims))) return rc;
-    if ((rc = upload(c, runs, &s.runs))) return rc;
+    {
+        DevScanRec end{};
+        end.code_inst = SC_END;
+        scan.push_back(end);  // the list scan reads one record ahead
+    }
+    if ((rc = upload(c, scan, &s.scan))) return rc;
+    if ((rc = upload(c, shade, &s.shade))) return rc;
+    if ((rc = upload(c, light_prims, &s.light_prims))) return rc;
     if ((rc = upload(c, entries, &s.entries))) return rc;
-    if ((rc = upload(c, lights, &s.lights))) return rc;
-    if ((rc = upload(c, mats, &s.materials))) return rc;
     if ((rc = upload(c, texs, &s.textures))) return rc;
     if ((rc = upload(c, images, &s.images))) return rc;
     if ((rc = upload(c, perlins, &s.perlins))) return rc;
@@ -426,7 +457,6 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     s.n_lights = d->n_lights;
     s.n_media = n_media;
     s.n_instances = (uint32_t)insts.size();
-    s.n_materials = d->n_materials;
     s.n_textures = d->n_textures;
     s.features = features;
     for (int a = 0; a < 3; ++a) s.background[a] = d->background[a];
