@@ -42,6 +42,8 @@ MIRT_DEV float norm_squared(V3 a) { return dot(a, a); }
 MIRT_DEV V3 normalize(V3 a) { return a / sqrtf(norm_squared(a)); }
 MIRT_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 MIRT_DEV float comp(V3 v, uint32_t i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+// per-component select (a struct-valued ?: makes hipcc index a two-element array in scratch memory)
+MIRT_DEV V3 select(bool c, V3 a, V3 b) { return V3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 
 // hardware approximations (about 1 ulp) for the shading code
 MIRT_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -58,6 +60,14 @@ MIRT_DEV float div_nr(float n, float d, float r) {
     float q = n * r;
     float e = __builtin_fmaf(-q, d, n);
     return __builtin_fmaf(e, r, q);
+}
+// sqrt(x) from v_rsq and one Newton step (x >= 0; the x == 0 case would be 0 * inf)
+MIRT_DEV float sqrt_nr(float x) {
+    float r = fast_rsq(x);
+    float s = x * r;
+    float e = __builtin_fmaf(-s, s, x);
+    float y = __builtin_fmaf(e, 0.5f * r, s);
+    return x == 0.f ? 0.f : y;
 }
 
 struct Ray {
@@ -227,11 +237,17 @@ MIRT_DEV bool sphere_hit_c(V3 center, float radius, const Ray& r, float t_min, f
     float c = norm_squared(oc) - radius * radius;
     float discriminant = half_b * half_b - a * c;
     if (discriminant < 0.f) return false;
-    float sqrtd = sqrtf(discriminant);
-    float root = (-half_b - sqrtd) / a;
-    if (root < t_min || root > t_max) {
-        root = (-half_b + sqrtd) / a;
-        if (root < t_min || root > t_max) return false;
+    // square root and the two quotients from the hardware estimates plus one Newton step each:
+    // correctly rounded except with probability ~2^-21
+    float sqrtd = sqrt_nr(discriminant);
+    float ra = fast_rcp(a);
+    // Accepting form: a NaN root (NaN ray) is a miss. In the reference a NaN root passes both range
+    // tests of geo.rs:100-104 and the NaN path is traced on to max_depth; a NaN ray only arises together
+    // with a NaN throughput (geo.rs:80,138), so the sample is NaN -> 0 (renderer.rs:107) either way.
+    float root = div_nr(-half_b - sqrtd, a, ra);
+    if (!(root >= t_min && root <= t_max)) {
+        root = div_nr(-half_b + sqrtd, a, ra);
+        if (!(root >= t_min && root <= t_max)) return false;
     }
     t_out = root;
     return true;
@@ -408,8 +424,12 @@ MIRT_DEV void bvh_leaf(const DevScene& s, const DevEntry& en, uint32_t slot, uin
 template <uint32_t F>
 MIRT_DEV void bvh_traverse(const DevScene& s, const DevEntry& en, const Ray& r, float t_min, float& closest, int& best,
                            uint32_t* stack, uint32_t stride) {
+    // A ray with a NaN component hits no primitive (see sphere_hit_c) but would pass every box test
+    // (min / max drop NaN operands) and visit the whole tree: stop it here.
+    const float nan_probe = (r.o.x + r.o.y + r.o.z) + (r.d.x + r.d.y + r.d.z);
+    if (nan_probe != nan_probe) return;
     LRay lr = make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
-    V3 inv_d = v3(1.f / lr.r.d.x, 1.f / lr.r.d.y, 1.f / lr.r.d.z);
+    const V3 inv_d = lr.rinv;  // 1-ulp reciprocals; slab() widens the far bound by more than that
     uint32_t sp = 0;
     uint32_t node = en.bvh_root;
     for (;;) {
@@ -498,7 +518,7 @@ MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim)
         }
         V3 on = fast_normalize(outward);
         front = dot(lr.d, on) < 0.f;
-        nl = front ? on : -on;
+        nl = select(front, on, -on);
     } else {
         // geo.rs:205-211
         uint32_t xi, yi, zi;
@@ -728,7 +748,7 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, co
         V3 refr = fast_normalize(perp + par);
         V3 refl_d = ray.d - (2.f * dot(h.n, ray.d)) * h.n;  // material.rs:75-77
         ray.o = h.p;
-        ray.d = reflect ? refl_d : refr;
+        ray.d = select(reflect, refl_d, refr);
         return true;                                        // attenuation 1, divisor 1
     }
     if ((F & F_MAT_ISOTROPIC) && mk == MK_ISOTROPIC) {
@@ -786,8 +806,9 @@ MIRT_DEV Ray camera_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t w
         xo = g.next();
         yo = g.next();
     }
-    float s = ((float)x + xo) / (float)(width - 1);
-    float t = ((float)y + yo) / (float)(height - 1);
+    const float wm1 = (float)(width - 1), hm1 = (float)(height - 1);
+    float s = div_nr((float)x + xo, wm1, fast_rcp(wm1));
+    float t = div_nr((float)y + yo, hm1, fast_rcp(hm1));
     Ray r;
     V3 target = ((v3(cam.llc) + s * v3(cam.horizontal)) + t * v3(cam.vertical)) - v3(cam.origin);
     if (PINHOLE) {

@@ -15,9 +15,14 @@
 namespace mirt {
 
 constexpr int kBlock = 256;
+// Waves per SIMD the register allocator is asked to fit (launch bound). Small list-only scenes are
+// VALU-issue bound and gain from 5-6 resident waves; the full-feature kernel needs its registers.
 #ifndef MIRT_WAVES
-#define MIRT_WAVES 4
+#define MIRT_WAVES 5
 #endif
+constexpr int waves_for(uint32_t features) {
+    return (features & (F_TEX_NOISE | F_TEX_IMAGE)) ? 3 : ((features & F_BVH) ? 4 : MIRT_WAVES);
+}
 
 // capacity of the per-block LDS copies of the tables shading indexes per lane
 constexpr uint32_t kLdsPrims = 64, kLdsInstances = 16, kLdsLights = 8;
@@ -43,7 +48,7 @@ __device__ __forceinline__ void copy_to_lds(T* dst, const T* src, uint32_t n) {
 // F: feature mask. LDS_TABLES: primitives / instances / materials / textures are copied to LDS once
 // per block and shading reads them there. PINHOLE: lens radius 0 and nothing moves.
 template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
-__global__ __launch_bounds__(kBlock, MIRT_WAVES) void render_fused_kernel(RenderArgs a) {
+__global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(RenderArgs a) {
     __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
     __shared__ DevPrim s_prims[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevShade s_shade[LDS_TABLES ? kLdsPrims : 1];

@@ -139,7 +139,14 @@ def test_accumulated_image_matches_oracle(rt, oracle, earth, name, spp, depth):
     assert np.isfinite(got).all()
     st = ctx.stats()
     assert st["samples"] == W * H * spp
-    assert abs(st["segments"] - int(cnt[0])) <= 0.002 * int(cnt[0]) + 2      # same paths -> same segment count
+    if name == "random":
+        # Shading points inside the glass light sphere give a NaN pdf and a NaN sampled direction
+        # (geo.rs:80,138). The reference keeps tracing that NaN ray until max_depth (every NaN comparison
+        # "hits"); the sample is NaN -> 0 either way (renderer.rs:107), so the GPU ends the path at once
+        # and traces fewer segments for the same image.
+        assert 0.90 * int(cnt[0]) <= st["segments"] <= 1.002 * int(cnt[0])
+    else:
+        assert abs(st["segments"] - int(cnt[0])) <= 0.002 * int(cnt[0]) + 2  # same paths -> same segment count
     close = np.isclose(got, want, rtol=5e-3, atol=5e-3 * spp * 0.05)
     assert close.all(axis=2).mean() > 0.97
     mean_g, mean_o = got.mean() / spp, want.mean() / spp
