@@ -13,6 +13,7 @@
 #include "bvh_build.h"
 #include "dev_types.h"
 #include "kernels.h"
+#include "wavefront.h"
 
 using namespace mirt;
 
@@ -33,6 +34,11 @@ struct mirt_ctx {
     size_t frame_dev_bytes = 0;
     unsigned long long* seg_counter = nullptr;
     mirt_stats stats{};
+    // wavefront kernel set: path state + queues for `wf_capacity` slots, counters mirrored in pinned memory
+    WfState wf{};
+    uint32_t wf_capacity = 0;
+    std::vector<void*> wf_allocs;
+    uint32_t* wf_counts_host = nullptr;
 };
 
 namespace {
@@ -160,6 +166,8 @@ void mirt_destroy(mirt_ctx* c) {
     if (c->accum_owned) (void)hipFree(c->accum_owned);
     if (c->frame_dev) (void)hipFree(c->frame_dev);
     if (c->seg_counter) (void)hipFree(c->seg_counter);
+    for (void* p : c->wf_allocs) (void)hipFree(p);
+    if (c->wf_counts_host) (void)hipHostFree(c->wf_counts_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -508,6 +516,91 @@ int mirt_frame_begin(mirt_ctx* c, uint32_t width, uint32_t height, float* accum_
     return MIRT_OK;
 }
 
+}  // extern "C"
+
+namespace {
+template <class T>
+int wf_alloc(mirt_ctx* c, T** out, size_t n) {
+    void* p = nullptr;
+    HIP_TRY(c, hipMalloc(&p, n * sizeof(T)));
+    c->wf_allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return MIRT_OK;
+}
+
+int wf_ensure(mirt_ctx* c, uint32_t slots) {
+    if (c->wf_capacity >= slots) return MIRT_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (void* p : c->wf_allocs) (void)hipFree(p);
+    c->wf_allocs.clear();
+    c->wf_capacity = 0;
+    int rc;
+    WfState st{};
+    if ((rc = wf_alloc(c, &st.rayo, slots))) return rc;
+    if ((rc = wf_alloc(c, &st.rayd, slots))) return rc;
+    if ((rc = wf_alloc(c, &st.thr, slots))) return rc;
+    if ((rc = wf_alloc(c, &st.ids, slots))) return rc;
+    if ((rc = wf_alloc(c, &st.hit_t, slots))) return rc;
+    if ((rc = wf_alloc(c, &st.q_new, slots))) return rc;
+    if ((rc = wf_alloc(c, &st.q_cur, slots))) return rc;
+    if ((rc = wf_alloc(c, &st.q_next, slots))) return rc;
+    if ((rc = wf_alloc(c, &st.q_mat, (size_t)slots * WF_KINDS))) return rc;
+    if ((rc = wf_alloc(c, &st.counts, (size_t)WF_N_COUNTS))) return rc;
+    if (!c->wf_counts_host) HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->wf_counts_host), 2 * WF_N_COUNTS * sizeof(uint32_t)));
+    c->wf = st;
+    c->wf_capacity = slots;
+    return MIRT_OK;
+}
+
+// generate -> extend -> shade per ray segment, driven from the host: after each iteration the queue
+// counters are read back (one small copy + stream sync) to size the next launches and detect the end.
+int render_wavefront(mirt_ctx* c, const mirt_render_params* p) {
+    const uint32_t n = p->width * p->height;
+    int rc = wf_ensure(c, n);
+    if (rc) return rc;
+    WfArgs a{};
+    a.scene = c->scene;
+    a.cam = c->cam;
+    a.accum = c->accum;
+    a.segment_counter = c->seg_counter;
+    a.width = p->width; a.height = p->height; a.capacity = c->wf_capacity;
+    a.sample_end = p->spp_begin + p->spp_count;
+    a.max_depth = p->max_depth; a.seed = p->seed; a.jitter = p->jitter;
+    uint32_t launches = 0;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    if (p->spp_count && p->max_depth) {
+        a.st = c->wf;
+        HIP_TRY(c, wf_launch_reset(a.st, n, p->spp_begin, c->stream));
+        uint32_t n_new = n, n_cont = 0;
+        uint32_t* up = c->wf_counts_host;
+        uint32_t* down = c->wf_counts_host + WF_N_COUNTS;
+        while (n_new || n_cont) {
+            for (uint32_t i = 0; i < WF_N_COUNTS; ++i) up[i] = 0;
+            up[WF_N_CUR] = n_cont;
+            HIP_TRY(c, hipMemcpyAsync(a.st.counts, up, WF_N_COUNTS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            a.n_new = n_new;
+            a.n_cur = n_cont + n_new;
+            HIP_TRY(c, wf_launch_generate(a, c->stream));
+            HIP_TRY(c, wf_launch_extend(a, c->stream));
+            HIP_TRY(c, wf_launch_shade(a, c->stream));
+            HIP_TRY(c, hipMemcpyAsync(down, a.st.counts, WF_N_COUNTS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            launches += 3;
+            n_new = down[WF_N_NEW];
+            n_cont = down[WF_N_NEXT];
+            std::swap(a.st.q_cur, a.st.q_next);
+        }
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    c->stats.samples += (uint64_t)n * p->spp_count;
+    c->stats.kernel_launches = launches;
+    c->stats.kernel_used = MIRT_KERNEL_WAVEFRONT;
+    return MIRT_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     if (!c) return MIRT_ERR_INVALID;
     if (!p) return fail(c, MIRT_ERR_INVALID, "mirt_render: params is NULL");
@@ -516,8 +609,9 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     if (!c->accum || p->width != c->width || p->height != c->height)
         return fail(c, MIRT_ERR_STATE, "mirt_render: width/height differ from mirt_frame_begin");
     if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, "mirt_render: sample range overflows 32 bits");
-    if (p->kernel == MIRT_KERNEL_WAVEFRONT) return fail(c, MIRT_ERR_INVALID, "mirt_render: wavefront kernel set not built in this version");
+    if (p->kernel > MIRT_KERNEL_WAVEFRONT) return fail(c, MIRT_ERR_INVALID, "mirt_render: unknown kernel selector");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (p->kernel == MIRT_KERNEL_WAVEFRONT) return render_wavefront(c, p);
     RenderArgs a{};
     a.scene = c->scene;
     a.cam = c->cam;

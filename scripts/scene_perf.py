@@ -9,9 +9,11 @@ for scene, spp, kw in [("cornell", 256, {}), ("smoke", 64, {}), ("random", 32, {
     ctx = rt.Context(0)
     ctx.scene_upload(sc)
     ctx.camera_set(rt.Camera.select_camera(W / H, scene))
-    ctx.frame_begin(W, H)
-    ctx.render(spp, 50 if not kw else 10, seed=0)
-    ctx.synchronize()
-    st = ctx.stats()
+    for kern in (rt.KERNEL_FUSED, rt.KERNEL_WAVEFRONT):
+      ctx.frame_begin(W, H)
+      ctx.render(spp, 50 if not kw else 10, seed=0, kernel=kern)
+      ctx.synchronize()
+      st = ctx.stats()
+      print('  kernel', kern, f"kernel_ms={st['kernel_ms']:.1f} Msamples/s={st['samples'] / st['kernel_ms'] / 1e3:.1f} Gseg/s={st['segments'] / st['kernel_ms'] / 1e6:.2f} launches={st['kernel_launches']}", flush=True)
     print(f"{scene:8s} {kw} prims={sc.desc.n_prims} spp={spp} kernel_ms={st['kernel_ms']:.1f} Msamples/s={st['samples'] / st['kernel_ms'] / 1e3:.1f} "
           f"Gseg/s={st['segments'] / st['kernel_ms'] / 1e6:.2f} seg/sample={st['segments'] / st['samples']:.2f}", flush=True)

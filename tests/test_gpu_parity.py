@@ -281,3 +281,28 @@ def test_error_paths(rt):
         ctx.scene_upload(bad)
     with pytest.raises(rt.MirtError):
         rt.Context(99)
+
+
+@pytest.mark.parametrize("name,spp", [("cornell", 16), ("smoke", 8), ("random", 8), ("final", 4), ("2psp", 8)])
+def test_wavefront_kernel_set_matches_fused(rt, oracle, earth, name, spp):
+    """The queue-based kernel set (generate -> extend -> shade per ray segment) draws from the same Philox
+    addresses as the fused kernel, so both produce the same samples; only the order of the float additions
+    into the accumulation buffer differs."""
+    orc, ctx, _ = make(rt, oracle, earth, name)
+    ctx.frame_begin(W, H)
+    ctx.render(spp, 50, seed=6, kernel=rt.KERNEL_FUSED)
+    fused = ctx.read_accum()
+    seg_fused = ctx.stats()["segments"]
+    ctx.frame_begin(W, H)
+    ctx.render(spp, 50, seed=6, kernel=rt.KERNEL_WAVEFRONT)
+    wave = ctx.read_accum()
+    st = ctx.stats()
+    assert st["kernel_used"] == rt.KERNEL_WAVEFRONT and st["segments"] == seg_fused
+    assert (wave[..., 3] == spp).all()
+    np.testing.assert_allclose(wave[..., :3], fused[..., :3], rtol=2e-5, atol=1e-5)
+    want, _ = orc.render_sums(spp, 50, seed=6)
+    assert np.isclose(wave[..., :3], want, rtol=5e-3, atol=5e-3 * spp * 0.05).all(axis=2).mean() > 0.97
+    # a sample range on top of an existing accumulation (progressive refinement)
+    ctx.render(3, 50, spp_begin=spp, seed=6, kernel=rt.KERNEL_WAVEFRONT)
+    more = ctx.read_accum()
+    assert (more[..., 3] == spp + 3).all()
