@@ -21,6 +21,10 @@ if ROOT not in sys.path:
 FLOP_PER_SEGMENT = 400.0       # algorithmic FLOP of one Cornell path segment (12 rect tests x 12 + sphere 30 +
                                # instance transform 15 + diffuse shade with the 2-light mixture pdf 200)
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X FP32 vector peak (packed FMA); 78.6 without packed math
+# HBM bytes of one render launch of the default workload, from rocprofv3 PMC passes
+# (profiles/r1/cornell_1080p_1024spp_v1_hbm_traffic_pmc.txt): 2 x FETCH_SIZE (gfx950 counts half of a wide read)
+# + WRITE_SIZE, in KiB. It is the float4 accumulation buffer read and written once: 2 x 33.2 MB.
+MEASURED_TRAFFIC_BYTES = {("cornell", 1920, 1080, 1024): (2 * 16310.875 + 33412.5) * 1024}
 
 
 def cpu_baseline(scene, width, height, depth, target_seconds=12.0):
@@ -51,6 +55,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the control flow)")
     args = ap.parse_args()
 
     import torch
@@ -63,8 +68,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        local_rank %= max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -75,6 +84,7 @@ def main():
     ctx.camera_set(rt.Camera.select_camera(W / H, args.scene))
     accum = torch.zeros(H * W * 4, dtype=torch.float32, device=dev)     # caller-owned, reducible by RCCL
     frame = torch.zeros(H * W * 4, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()   # the fills above run on torch's stream, the renderer on its own
 
     def step():
         ctx.frame_begin(W, H, accum.data_ptr())
@@ -124,7 +134,8 @@ def main():
             "config": {"workload": f"{args.scene} {W}x{H}, {spp} spp per GPU, max depth {args.depth}, light+cosine mixture pdf",
                        "samples_per_step": samples_per_step, "parallelism": f"spp-range x{world}" + (" + RCCL reduce" if world > 1 else "")},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": MEASURED_TRAFFIC_BYTES.get((args.scene, W, H, spp)), "traffic_unit": "bytes per launch (PMC, separate run)",
                          "kernel": "render_fused_kernel", "avg_launch_ms": kernel_ms / max(launches, 1),
                          "segments_per_sample": segments / (W * H * spp * args.steps),
                          "gsegments_per_s": segments / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,

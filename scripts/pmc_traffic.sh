@@ -1,0 +1,21 @@
+#!/bin/bash
+# usage: scripts/pmc_traffic.sh <tag> <scene> <spp> — HBM traffic of the render kernel: FETCH_SIZE and WRITE_SIZE
+# in separate rocprofv3 --pmc passes (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2).
+TAG=$1; SCENE=${2:-cornell}; SPP=${3:-1024}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/traffic_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout -s KILL 120 rocprofv3 --pmc $c --output-format csv -d $OUT/$c -- python3 $GRAFT_REPO_ROOT/scripts/prof_render.py $SCENE $SPP > $OUT/$c.log 2>&1
+  echo "pass $c rc=$?"
+done
+python3 - <<PY
+import csv, glob, collections
+tot = collections.defaultdict(float); n = collections.defaultdict(int)
+for f in glob.glob("$OUT/*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        if "render_fused" in r["Kernel_Name"]:
+            tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+for k in sorted(tot): print(k, "sum", tot[k], "dispatch rows", n[k])
+PY
