@@ -153,6 +153,9 @@ typedef struct mirt_stats {
     double kernel_ms;      /* GPU time of the last mirt_render, HIP events on the render stream */
     uint32_t kernel_launches; /* launches in the last mirt_render */
     uint32_t kernel_used;  /* MIRT_KERNEL_FUSED or MIRT_KERNEL_WAVEFRONT */
+    uint64_t lane_slots;   /* fused kernel: 64 x loop iterations summed over waves; segments / lane_slots =
+                              share of lane-iterations that traced a segment (the rest idled in a wave whose
+                              other lanes had longer paths) */
 } mirt_stats;
 
 /* ---- entry points --------------------------------------------------------------------------- */

@@ -155,9 +155,16 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(Rend
         v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += (float)a.spp_count;
         a.accum[pixel] = v;
     }
-    // one atomic per wave for the segment count
-    for (int off = 32; off > 0; off >>= 1) segments += __shfl_down(segments, off);
-    if ((threadIdx.x & 63u) == 0 && a.segment_counter) atomicAdd(a.segment_counter, (unsigned long long)segments);
+    // one atomic per wave for the segment count, one for 64 x the wave's loop count (= its longest lane)
+    uint32_t longest = segments;
+    for (int off = 32; off > 0; off >>= 1) {
+        segments += __shfl_down(segments, off);
+        longest = max(longest, (uint32_t)__shfl_down(longest, off));
+    }
+    if ((threadIdx.x & 63u) == 0 && a.segment_counter) {
+        atomicAdd(a.segment_counter, (unsigned long long)segments);
+        atomicAdd(a.segment_counter + 1, 64ull * longest);
+    }
 }
 
 template <uint32_t F>

@@ -152,8 +152,8 @@ int mirt_create(int device, mirt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(c->seg_counter, 0, sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->seg_counter, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     *out = c;
     return MIRT_OK;
 }
@@ -511,7 +511,7 @@ int mirt_frame_begin(mirt_ctx* c, uint32_t width, uint32_t height, float* accum_
     c->width = width;
     c->height = height;
     HIP_TRY(c, hipMemsetAsync(c->accum, 0, pixels * sizeof(float4), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->seg_counter, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->seg_counter, 0, 2 * sizeof(unsigned long long), c->stream));
     c->stats = mirt_stats{};
     return MIRT_OK;
 }
@@ -759,9 +759,10 @@ int mirt_get_stats(mirt_ctx* c, mirt_stats* out) {
     if (!c || !out) return MIRT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long seg = 0;
-    HIP_TRY(c, hipMemcpy(&seg, c->seg_counter, sizeof(seg), hipMemcpyDeviceToHost));
-    c->stats.segments = seg;
+    unsigned long long seg[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(seg, c->seg_counter, sizeof(seg), hipMemcpyDeviceToHost));
+    c->stats.segments = seg[0];
+    c->stats.lane_slots = seg[1];
     if (c->stats.kernel_launches) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.kernel_ms = ms;

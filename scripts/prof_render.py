@@ -16,4 +16,4 @@ ctx.render(spp, 50, seed=0)
 ctx.synchronize()
 st = ctx.stats()
 print(scene, W, H, spp, "kernel_ms", st["kernel_ms"], "Msamples/s", st["samples"] / st["kernel_ms"] / 1e3,
-      "Gseg/s", st["segments"] / st["kernel_ms"] / 1e6, "seg/sample", st["segments"] / st["samples"])
+      "Gseg/s", st["segments"] / st["kernel_ms"] / 1e6, "seg/sample", st["segments"] / st["samples"], "lane occupancy of loop", st["segments"] / max(st["lane_slots"], 1))
