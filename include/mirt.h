@@ -191,6 +191,10 @@ int mirt_resolve_rgba8_device(mirt_ctx* ctx, uint8_t* frame_device, size_t len);
 
 /* Copy the accumulation buffer to the host (n == width*height*4 floats). Blocks. */
 int mirt_read_accum(mirt_ctx* ctx, float* rgba, size_t n);
+/* Replace the accumulation buffer's contents from the host (n == width*height*4 floats): resume of an
+ * interrupted progressive render from a saved mirt_read_accum() image; continue with spp_begin = the
+ * sample count it holds. Blocks. No counterpart in the reference, which restarts every draw. */
+int mirt_write_accum(mirt_ctx* ctx, const float* rgba, size_t n);
 /* Device address of the accumulation buffer in use. */
 int mirt_accum_device_ptr(mirt_ctx* ctx, float** out);
 

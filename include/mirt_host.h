@@ -32,6 +32,10 @@ int mirt_host_draw(int device, const char* name, uint32_t width, uint32_t height
                    uint32_t seed, uint32_t scene_seed, int random_num, const uint8_t* earth_rgba, uint32_t earth_width,
                    uint32_t earth_height, uint8_t* frame, size_t frame_len);
 
+/* image::save_buffer(path, &pixels, width, height, ColorType::Rgba8) of the image mode (cli.rs:31-38):
+ * writes the RGBA8 frame (top row first) as a PNG file. */
+int mirt_host_save_png(const char* path, const uint8_t* rgba, uint32_t width, uint32_t height);
+
 const char* mirt_host_last_error(void);
 
 #ifdef __cplusplus

@@ -22,10 +22,11 @@ KERNEL_AUTO, KERNEL_FUSED, KERNEL_WAVEFRONT = 0, 1, 2
 # every symbol include/mirt.h and include/mirt_host.h declare
 EXPORTS = [
     "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_scene_upload", "mirt_camera_set", "mirt_frame_begin",
-    "mirt_render", "mirt_resolve_rgba8", "mirt_resolve_rgba8_device", "mirt_read_accum", "mirt_accum_device_ptr",
+    "mirt_render", "mirt_resolve_rgba8", "mirt_resolve_rgba8_device", "mirt_read_accum", "mirt_write_accum",
+    "mirt_accum_device_ptr",
     "mirt_first_hit", "mirt_ray_color", "mirt_synchronize", "mirt_get_stats", "mirt_philox4x32_10",
     "mirt_host_select_scene", "mirt_host_scene_desc", "mirt_host_scene_free", "mirt_host_select_camera",
-    "mirt_host_draw", "mirt_host_last_error",
+    "mirt_host_draw", "mirt_host_save_png", "mirt_host_last_error",
 ]
 
 
@@ -125,6 +126,7 @@ def lib():
         L.mirt_resolve_rgba8.argtypes = [vp, vp, sz]
         L.mirt_resolve_rgba8_device.argtypes = [vp, vp, sz]
         L.mirt_read_accum.argtypes = [vp, vp, sz]
+        L.mirt_write_accum.argtypes = [vp, vp, sz]
         L.mirt_accum_device_ptr.argtypes = [vp, C.POINTER(vp)]
         L.mirt_first_hit.argtypes = [vp, vp, sz, u32, vp, vp, vp]
         L.mirt_ray_color.argtypes = [vp, vp, sz, u32, u32, u32, vp]
@@ -139,6 +141,7 @@ def lib():
         L.mirt_host_scene_free.restype = None
         L.mirt_host_select_camera.argtypes = [C.c_float, C.c_char_p, C.POINTER(mirt_camera)]
         L.mirt_host_draw.argtypes = [C.c_int, C.c_char_p, u32, u32, u32, u32, u32, u32, C.c_int, vp, u32, u32, vp, sz]
+        L.mirt_host_save_png.argtypes = [C.c_char_p, vp, u32, u32]
         L.mirt_host_last_error.restype = C.c_char_p
         _lib = L
     return _lib
@@ -154,6 +157,15 @@ def philox4x32_10(key, ctr):
     out = np.zeros(4, dtype=np.uint32)
     lib().mirt_philox4x32_10(_ptr(k), _ptr(c), _ptr(out))
     return out
+
+
+def save_png(path, frame):
+    """image::save_buffer(path, &pixels, w, h, Rgba8) (cli.rs:31): frame is uint8 [H, W, 4], top row first."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    if frame.ndim != 3 or frame.shape[2] != 4:
+        raise ValueError("frame must be uint8 [H, W, 4]")
+    if lib().mirt_host_save_png(os.fsencode(path), _ptr(frame), frame.shape[1], frame.shape[0]) != MIRT_OK:
+        raise MirtError(lib().mirt_host_last_error().decode())
 
 
 def load_earthmap():
@@ -274,6 +286,13 @@ class Context:
         out = np.zeros((self.height, self.width, 4), dtype=np.float32)
         self._check(lib().mirt_read_accum(self._c, _ptr(out), out.size))
         return out
+
+    def write_accum(self, accum):
+        """Restore a saved read_accum() image (checkpoint resume); continue with spp_begin = its sample count."""
+        a = np.ascontiguousarray(accum, dtype=np.float32)
+        if a.shape != (self.height, self.width, 4):
+            raise ValueError(f"accum must be float32 [{self.height}, {self.width}, 4]")
+        self._check(lib().mirt_write_accum(self._c, _ptr(a), a.size))
 
     def accum_device_ptr(self):
         p = C.c_void_p()

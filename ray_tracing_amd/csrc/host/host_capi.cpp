@@ -1,6 +1,7 @@
 // C entry points of the host-side scene / camera / renderer mirror (include/mirt_host.h).
 #include <string>
 #include "../../../include/mirt_host.h"
+#include "png_writer.hpp"
 #include "renderer.hpp"
 
 struct mirt_host_scene {
@@ -59,6 +60,17 @@ int mirt_host_draw(int device, const char* name, uint32_t width, uint32_t height
         r.max_depth = max_depth;
         r.seed = seed;
         r.draw(frame, frame_len);
+        return MIRT_OK;
+    } catch (const std::exception& e) {
+        g_host_err = e.what();
+        return MIRT_ERR_INVALID;
+    }
+}
+
+int mirt_host_save_png(const char* path, const uint8_t* rgba, uint32_t width, uint32_t height) {
+    if (!path || !rgba) { g_host_err = "mirt_host_save_png: NULL argument"; return MIRT_ERR_INVALID; }
+    try {
+        rt::png_save_rgba8(path, rgba, width, height);
         return MIRT_OK;
     } catch (const std::exception& e) {
         g_host_err = e.what();

@@ -678,6 +678,16 @@ int mirt_read_accum(mirt_ctx* c, float* rgba, size_t n) {
     return MIRT_OK;
 }
 
+int mirt_write_accum(mirt_ctx* c, const float* rgba, size_t n) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (!c->accum) return fail(c, MIRT_ERR_STATE, "mirt_write_accum: no frame begun");
+    if (!rgba || n != (size_t)c->width * c->height * 4) return fail(c, MIRT_ERR_INVALID, "mirt_write_accum: n != width*height*4");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpyAsync(c->accum, rgba, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MIRT_OK;
+}
+
 int mirt_accum_device_ptr(mirt_ctx* c, float** out) {
     if (!c || !out) return MIRT_ERR_INVALID;
     if (!c->accum) return fail(c, MIRT_ERR_STATE, "mirt_accum_device_ptr: no frame begun");

@@ -130,3 +130,31 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hpp", ".cpp", ".hip")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower() or f == "__init__.py" and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_png_writer_round_trips(rt, tmp_path):
+    """image::save_buffer(.., Rgba8) of cli.rs:31-38: the file decodes to the frame that was written."""
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    for shape in ((1, 1, 4), (7, 13, 4), (108, 192, 4)):
+        frame = rng.integers(0, 256, shape, dtype=np.uint8)
+        path = tmp_path / f"f{shape[0]}.png"
+        rt.save_png(str(path), frame)
+        im = Image.open(path)
+        assert im.mode == "RGBA" and im.size == (shape[1], shape[0])
+        assert (np.asarray(im) == frame).all()
+    with pytest.raises(ValueError):
+        rt.save_png(str(tmp_path / "bad.png"), np.zeros((4, 4, 3), dtype=np.uint8))
+    with pytest.raises(rt.MirtError):
+        rt.save_png(str(tmp_path / "no_such_dir" / "x.png"), np.zeros((2, 2, 4), dtype=np.uint8))
+
+
+def test_cli_flags_and_defaults_follow_the_reference():
+    from ray_tracing_amd import cli
+    a = cli.parse([])
+    assert (a.max_depth, a.sample_count, a.down_scale, a.scene) == (50, 100, 10, "random")     # cli.rs:11-18
+    a = cli.parse(["-m", "5", "-s", "1024", "-d", "1", "--scene", "cornell"])
+    assert (a.max_depth, a.sample_count, a.down_scale, a.scene) == (5, 1024, 1, "cornell")
+    assert (cli.WIDTH, cli.HEIGHT) == (1920, 1080)                                               # lib.rs:42-43
+    with pytest.raises(SystemExit):
+        cli.parse(["-d", "0"])

@@ -4,6 +4,7 @@ properties of the reference's samplers (src/rand_gen.rs, src/pdf.rs, src/onb.rs,
 import math
 
 import numpy as np
+import pytest
 
 from conftest import kat_rays
 
@@ -146,3 +147,17 @@ def test_all_scenes_build_and_render(oracle, earth):
             assert r.num_leaf_ids == n_ids, name
         sums, _ = r.render_sums(2, 5, seed=0)
         assert np.isfinite(sums).all() and sums.sum() > 0, name
+
+
+@pytest.mark.parametrize("name", ["cornell", "smoke", "random", "final", "2sp", "2psp", "earth", "simplelight"])
+def test_oracle_reproduces_committed_first_hit_grid(oracle, earth, name):
+    """tests/golden/first_hit_<scene>.npz freezes the oracle: a change to it (or to the compiler flags it is
+    built with) that moves a first hit shows up here before it can move the device tests' target."""
+    import os
+    from conftest import ROOT
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"first_hit_{name}.npz"))
+    orc = oracle.OracleRenderer(name, 64, 36, earth_rgba=earth if name in ("earth", "final") else None)
+    ids, t = orc.first_hit(orc.camera_rays(0.5), seed=11)
+    assert (ids == z["prim_id"].reshape(-1)).all()
+    hit = ids >= 0
+    assert (t[hit] == z["t"].reshape(-1)[hit]).all()
