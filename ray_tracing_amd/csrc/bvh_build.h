@@ -19,9 +19,11 @@ struct BuildObject {
 
 class BvhBuilder {
    public:
-    // max_depth bounds the traversal stack; leaf_max = objects per leaf.
-    BvhBuilder(std::vector<DevBvhNode>& nodes, std::vector<uint32_t>& slots, int max_depth, uint32_t leaf_max)
-        : nodes_(nodes), slots_(slots), max_depth_(max_depth), leaf_max_(leaf_max) {}
+    // max_depth bounds the traversal stack; leaf_max = objects per leaf; an object is prims_per_object
+    // consecutive primitives. `slots` receives the primitive indices of the leaves in tree order; a leaf
+    // reference is (first slot, number of slots).
+    BvhBuilder(std::vector<DevBvhNode>& nodes, std::vector<uint32_t>& slots, int max_depth, uint32_t leaf_max, uint32_t prims_per_object)
+        : nodes_(nodes), slots_(slots), max_depth_(max_depth), leaf_max_(leaf_max), ppo_(prims_per_object) {}
 
     // Returns the index of the root node.
     uint32_t build(std::vector<BuildObject>& objs) {
@@ -47,6 +49,7 @@ class BvhBuilder {
     std::vector<uint32_t>& slots_;
     int max_depth_;
     uint32_t leaf_max_;
+    uint32_t ppo_;
 
     static void set_child(DevBvhNode& nd, int which, const Ref& r) {
         float* lo = which ? nd.lo1 : nd.lo0;
@@ -80,8 +83,9 @@ class BvhBuilder {
         size_t n = end - begin;
         if (n <= leaf_max_) {
             r.c = (uint32_t)slots_.size();
-            r.n = (uint32_t)n;
-            for (size_t i = begin; i < end; ++i) slots_.push_back(objs[i].first_prim);
+            r.n = (uint32_t)n * ppo_;
+            for (size_t i = begin; i < end; ++i)
+                for (uint32_t q = 0; q < ppo_; ++q) slots_.push_back(objs[i].first_prim + q);
             return r;
         }
         size_t mid = begin;

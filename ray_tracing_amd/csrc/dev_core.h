@@ -389,9 +389,22 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
 
 // ---------------------------------------------------------------------------------------------
 // flattened BVH (the device form of aabb.rs BVHNode): 64-byte nodes holding both child boxes,
-// per-lane traversal stack in LDS
+// leaves as runs of 32-byte primitive records, per-lane traversal stack in LDS.
+//
+// Traversal is written as a resumable walk: `Walk` holds everything a lane needs to continue
+// (local ray, current reference, stack depth, entry, closest hit so far), walk_node() consumes one
+// interior reference and walk_leaf() one leaf reference. A caller that only wants the answer loops
+// until the walk is idle (walk_run); the render kernel for hierarchy scenes interleaves the steps of
+// its 64 lanes with shading so that lanes whose walk ended early do not wait for the longest one.
 // ---------------------------------------------------------------------------------------------
 constexpr int kBvhStackDepth = 32;
+constexpr uint32_t kWalkIdle = 0xffffffffu;   // no reference: the walk is over
+constexpr uint32_t kRefLeaf = 0x80000000u;    // leaf reference: bit 31, (records - 1) << 27, first record
+constexpr uint32_t kRefLeafIndexMask = (1u << 27) - 1u;
+
+MIRT_DEV uint32_t child_ref(uint32_t c, uint32_t n) { return n ? (kRefLeaf | ((n - 1u) << 27) | c) : c; }
+MIRT_DEV bool ref_is_leaf(uint32_t ref) { return ref != kWalkIdle && (ref & kRefLeaf); }
+MIRT_DEV bool ref_is_node(uint32_t ref) { return !(ref & kRefLeaf); }
 
 MIRT_DEV bool slab(const float* lo, const float* hi, V3 o, V3 inv_d, float t_min, float t_max, float& t_near) {
     float tx0 = (lo[0] - o.x) * inv_d.x, tx1 = (hi[0] - o.x) * inv_d.x;
@@ -403,76 +416,144 @@ MIRT_DEV bool slab(const float* lo, const float* hi, V3 o, V3 inv_d, float t_min
     return tn <= tf * 1.0000004f;
 }
 
-template <uint32_t F>
-MIRT_DEV void bvh_leaf(const DevScene& s, const DevEntry& en, uint32_t slot, uint32_t n, const LRay& lr, float t_min,
-                       float& closest, int& best) {
-    for (uint32_t j = 0; j < n; ++j) {
-        uint32_t first = s.bvh_objects[slot + j];
-        for (uint32_t q = 0; q < en.prims_per_object; ++q) {
-            const DevPrim& p = s.prims[first + q];
-            float t;
-            if (leaf_hit<F, false>(p, lr, t_min, closest, t)) {
-                closest = t;
-                best = (int)(first + q);
-            }
-        }
-    }
-}
+struct Walk {
+    LRay lr;         // the ray in the frame of the entry being walked
+    uint32_t ref;    // current reference (interior node index or leaf run) or kWalkIdle
+    uint32_t sp;     // entries on this lane's stack
+    uint32_t entry;  // world entry being walked
+    float closest;   // t of the closest hit so far (starts at the list scans' result)
+    int best;        // its primitive, -1 = none
+};
 
-// BVHNode::hit (aabb.rs:112-126) on the flattened tree. `stack` is this lane's column of an LDS
-// array laid out [level][lane] (stride = blockDim.x words), so pushes and pops are conflict-free.
+// Start the walk of the first hierarchy entry at index >= w.entry, or go idle when there is none.
+// A ray with a NaN component hits no primitive (see sphere_hit_c) but would pass every box test
+// (min / max drop NaN operands) and visit the whole tree: it goes idle at once.
 template <uint32_t F>
-MIRT_DEV void bvh_traverse(const DevScene& s, const DevEntry& en, const Ray& r, float t_min, float& closest, int& best,
-                           uint32_t* stack, uint32_t stride) {
-    // A ray with a NaN component hits no primitive (see sphere_hit_c) but would pass every box test
-    // (min / max drop NaN operands) and visit the whole tree: stop it here.
+MIRT_DEV void walk_next_entry(const DevScene& s, const Ray& r, Walk& w) {
+    w.ref = kWalkIdle;
+    w.sp = 0;
     const float nan_probe = (r.o.x + r.o.y + r.o.z) + (r.d.x + r.d.y + r.d.z);
     if (nan_probe != nan_probe) return;
-    LRay lr = make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
-    const V3 inv_d = lr.rinv;  // 1-ulp reciprocals; slab() widens the far bound by more than that
-    uint32_t sp = 0;
-    uint32_t node = en.bvh_root;
-    for (;;) {
-        const DevBvhNode& nd = s.bvh_nodes[node];
-        float tn0, tn1;
-        bool h0 = slab(nd.lo0, nd.hi0, lr.r.o, inv_d, t_min, closest, tn0);
-        bool h1 = nd.c1 != 0xffffffffu && slab(nd.lo1, nd.hi1, lr.r.o, inv_d, t_min, closest, tn1);
-        uint32_t c0 = nd.c0, n0 = nd.n0, c1 = nd.c1, n1 = nd.n1;
-        // leaves are intersected immediately; interior children are visited near-first
-        if (h0 && n0) {
-            bvh_leaf<F>(s, en, c0, n0, lr, t_min, closest, best);
-            h0 = false;
-        }
-        if (h1 && n1) {
-            if (tn1 <= closest) bvh_leaf<F>(s, en, c1, n1, lr, t_min, closest, best);
-            h1 = false;
-        }
-        if (h0 && h1) {
-            bool first0 = tn0 <= tn1;
-            uint32_t far = first0 ? c1 : c0;
-            node = first0 ? c0 : c1;
-            if (sp < (uint32_t)kBvhStackDepth) stack[(sp++) * stride] = far;
-            continue;
-        }
-        if (h0) { node = c0; continue; }
-        if (h1) { node = c1; continue; }
-        if (sp == 0) break;
-        node = stack[(--sp) * stride];
+    for (uint32_t e = w.entry; e < s.n_entries; ++e) {
+        const DevEntry& en = s.entries[e];
+        if (en.kind != EK_BVH) continue;
+        w.entry = e;
+        // 1-ulp reciprocals; slab() widens the far bound by more than that
+        w.lr = make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
+        w.ref = en.bvh_root;
+        return;
     }
 }
 
-// scene.world.hit(r, 0.001, inf) — renderer.rs:201.
+// The walk ran out of references in its entry: pop, or move on to the next hierarchy entry.
+template <uint32_t F>
+MIRT_DEV void walk_pop(const DevScene& s, const Ray& r, Walk& w, const uint32_t* stack, uint32_t stride) {
+    if (w.sp) {
+        w.ref = stack[(--w.sp) * stride];
+    } else {
+        ++w.entry;
+        walk_next_entry<F>(s, r, w);
+    }
+}
+
+// BVHNode::hit (aabb.rs:112-126) for one interior node: test both child boxes against [t_min,
+// closest], continue with the nearer hit child and push the other. `stack` is this lane's column of
+// an LDS array laid out [level][lane] (stride = blockDim.x words): pushes and pops are conflict-free.
+template <uint32_t F>
+MIRT_DEV void walk_node(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t* stack, uint32_t stride) {
+    const DevBvhNode& nd = s.bvh_nodes[w.ref];
+    float tn0, tn1;
+    const bool h0 = slab(nd.lo0, nd.hi0, w.lr.r.o, w.lr.rinv, t_min, w.closest, tn0);
+    const bool h1 = nd.c1 != 0xffffffffu && slab(nd.lo1, nd.hi1, w.lr.r.o, w.lr.rinv, t_min, w.closest, tn1);
+    const uint32_t r0 = child_ref(nd.c0, nd.n0), r1 = child_ref(nd.c1, nd.n1);
+    if (h0 && h1) {
+        const bool first0 = tn0 <= tn1;
+        w.ref = first0 ? r0 : r1;
+        if (w.sp < (uint32_t)kBvhStackDepth) stack[(w.sp++) * stride] = first0 ? r1 : r0;
+    } else if (h0) {
+        w.ref = r0;
+    } else if (h1) {
+        w.ref = r1;
+    } else {
+        walk_pop<F>(s, r, w, stack, stride);
+    }
+}
+
+// One primitive record of a leaf (the record's kind differs from lane to lane, so the rectangle's axes
+// are chosen with per-lane selects). Same tests as the list scan: geo.rs:89-105, geo.rs:196-204.
+template <uint32_t F>
+MIRT_DEV bool leaf_rec_hit(const DevScene& s, const DevScanRec& rec, const LRay& l, float t_min, float t_max, float& t_out) {
+    const uint32_t code = rec.code_inst & 0xffu;
+    if ((F & F_SPHERE) && (!(F & (F_RECT | F_MOVING)) || code == SC_SPHERE))
+        return sphere_hit_c(v3(rec.f), rec.f[3], l.r, t_min, t_max, t_out);
+    if ((F & F_MOVING) && code == SC_SPHERE_MOVING) {
+        const DevPrim& q = s.prims[rec.prim];
+        return sphere_hit_c(sphere_center<F>(q, l.r.time), q.a[3], l.r, t_min, t_max, t_out);
+    }
+    if ((F & F_RECT) && code >= SC_RECT_XY && code <= SC_RECT_YZ) {
+        uint32_t xi, yi, zi;
+        axis_indexes(code - SC_RECT_XY, xi, yi, zi);
+        float t = div_nr(rec.f[0] - comp(l.r.o, zi), comp(l.r.d, zi), comp(l.rinv, zi));
+        float x = comp(l.r.o, xi) + t * comp(l.r.d, xi);
+        float y = comp(l.r.o, yi) + t * comp(l.r.d, yi);
+        t_out = t;
+        return (t >= t_min) & (t <= t_max) & (x >= rec.f[1]) & (x <= rec.f[2]) & (y >= rec.f[3]) & (y <= rec.f[4]);
+    }
+    return false;
+}
+
+// The records of one leaf, in object order (a later record wins a tie, as in ray.rs:123-133).
+template <uint32_t F>
+MIRT_DEV void walk_leaf(const DevScene& s, const Ray& r, float t_min, Walk& w, const uint32_t* stack, uint32_t stride) {
+    const uint32_t first = w.ref & kRefLeafIndexMask, n = ((w.ref >> 27) & 15u) + 1u;
+    for (uint32_t j = 0; j < n; ++j) {
+        const DevScanRec& rec = s.bvh_leaves[first + j];
+        float t;
+        if (leaf_rec_hit<F>(s, rec, w.lr, t_min, w.closest, t)) {
+            w.closest = t;
+            w.best = (int)rec.prim;
+        }
+    }
+    walk_pop<F>(s, r, w, stack, stride);
+}
+
+// Walk every hierarchy entry to the end.
+template <uint32_t F>
+MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t* stack, uint32_t stride) {
+    while (w.ref != kWalkIdle) {
+        if (ref_is_node(w.ref)) walk_node<F>(s, r, t_min, w, stack, stride);
+        else walk_leaf<F>(s, r, t_min, w, stack, stride);
+    }
+}
+
+// The list entries of the world, in world order (HittableList::hit, ray.rs:123-133).
+template <uint32_t F>
+MIRT_DEV void world_lists(const DevScene& s, const Ray& r, const DrawKey& key, float& closest, int& best) {
+    for (uint32_t e = 0; e < s.n_entries; ++e) {
+        const DevEntry& en = s.entries[e];
+        if (!(F & F_BVH) || en.kind != EK_BVH) list_scan<F, true>(s, en.scan_first, en.scan_count, r, 0.001f, key, closest, best);
+    }
+}
+
+// scene.world.hit(r, 0.001, inf) — renderer.rs:201. The list entries are scanned first and the
+// hierarchy entries walked after them, each group in world order, so the hierarchies start with the
+// lists' closest hit as their far bound. The closest hit does not depend on the order; only an exact
+// tie between a list member and a hierarchy member placed before it would go to the other primitive.
 template <uint32_t F>
 MIRT_DEV void world_hit(const DevScene& s, const Ray& r, const DrawKey& key, uint32_t* stack, uint32_t stride, float& t_out,
                         int& prim_out) {
     float closest = MIRT_INF;
     int best = -1;
-    for (uint32_t e = 0; e < s.n_entries; ++e) {
-        const DevEntry& en = s.entries[e];
-        if ((F & F_BVH) && en.kind == EK_BVH)
-            bvh_traverse<F>(s, en, r, 0.001f, closest, best, stack, stride);
-        else
-            list_scan<F, true>(s, en.scan_first, en.scan_count, r, 0.001f, key, closest, best);
+    world_lists<F>(s, r, key, closest, best);
+    if (F & F_BVH) {
+        Walk w;
+        w.entry = 0;
+        w.closest = closest;
+        w.best = best;
+        walk_next_entry<F>(s, r, w);
+        walk_run<F>(s, r, 0.001f, w, stack, stride);
+        closest = w.closest;
+        best = w.best;
     }
     t_out = closest;
     prim_out = best;

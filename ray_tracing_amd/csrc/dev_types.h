@@ -87,9 +87,8 @@ struct __attribute__((aligned(16))) DevEntry {
 };
 
 // 64-byte node holding the boxes of both children, so one interior step is one 64-byte fetch.
-// Child i: n_i == 0 -> interior node index c_i; n_i > 0 -> leaf of n_i objects starting at slot c_i
-// of bvh_objects (each slot is the index of the object's first prim). c1 == 0xffffffff marks a
-// missing second child (single-leaf tree).
+// Child i: n_i == 0 -> interior node index c_i; n_i > 0 -> leaf of n_i primitive records (at most 16)
+// starting at record c_i of bvh_leaves. c1 == 0xffffffff marks a missing second child (single-leaf tree).
 struct __attribute__((aligned(16))) DevBvhNode {
     float lo0[3];
     uint32_t c0;
@@ -129,7 +128,7 @@ struct DevScene {
     const DevPerlin* perlins;
     const DevInstance* instances;
     const DevBvhNode* bvh_nodes;
-    const uint32_t* bvh_objects;
+    const DevScanRec* bvh_leaves;  // leaf primitive records in tree order (same record form as the list scans)
     uint32_t n_prims, n_entries, n_lights, n_media;
     uint32_t n_instances, n_textures;
     uint32_t features;

@@ -242,26 +242,27 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     }
     // ---- list-scan records: one 32-byte record per list member, in list order
     std::vector<DevScanRec> scan;
+    auto scan_record = [&](uint32_t i) {
+        const mirt_prim& p = d->prims[i];
+        DevScanRec r{};
+        uint32_t code;
+        if (p.kind == MIRT_PRIM_SPHERE) {
+            code = (p.flags & MIRT_PRIM_MOVING) ? SC_SPHERE_MOVING : SC_SPHERE;
+            for (int a = 0; a < 3; ++a) r.f[a] = p.center0[a];
+            r.f[3] = p.radius;
+        } else if (p.kind == MIRT_PRIM_RECT) {
+            code = SC_RECT_XY + p.axis;
+            r.f[0] = p.k; r.f[1] = p.lo[0]; r.f[2] = p.hi[0]; r.f[3] = p.lo[1]; r.f[4] = p.hi[1];
+        } else {
+            code = SC_MEDIUM;
+        }
+        r.code_inst = code | (p.instance << 8);
+        r.prim = i;
+        return r;
+    };
     auto make_scan = [&](uint32_t first, uint32_t count, uint32_t* scan_first, uint32_t* scan_count) {
         *scan_first = (uint32_t)scan.size();
-        for (uint32_t i = first; i < first + count; ++i) {
-            const mirt_prim& p = d->prims[i];
-            DevScanRec r{};
-            uint32_t code;
-            if (p.kind == MIRT_PRIM_SPHERE) {
-                code = (p.flags & MIRT_PRIM_MOVING) ? SC_SPHERE_MOVING : SC_SPHERE;
-                for (int a = 0; a < 3; ++a) r.f[a] = p.center0[a];
-                r.f[3] = p.radius;
-            } else if (p.kind == MIRT_PRIM_RECT) {
-                code = SC_RECT_XY + p.axis;
-                r.f[0] = p.k; r.f[1] = p.lo[0]; r.f[2] = p.hi[0]; r.f[3] = p.lo[1]; r.f[4] = p.hi[1];
-            } else {
-                code = SC_MEDIUM;
-            }
-            r.code_inst = code | (p.instance << 8);
-            r.prim = i;
-            scan.push_back(r);
-        }
+        for (uint32_t i = first; i < first + count; ++i) scan.push_back(scan_record(i));
         *scan_count = (uint32_t)scan.size() - *scan_first;
     };
     if (d->n_instances >= (1u << 24)) return bad("too many instances");
@@ -412,7 +413,9 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
                     for (int a = 0; a < 3; ++a) { o.lo[a] = std::min(o.lo[a], lo[a]); o.hi[a] = std::max(o.hi[a], hi[a]); }
                 }
             }
-            BvhBuilder builder(nodes, slots, 32, q.prims_per_object > 1 ? 1u : 2u);
+            const uint32_t leaf_objects = q.prims_per_object > 1 ? 1u : 2u;
+            if (leaf_objects * q.prims_per_object > 16u) return bad("entry " + std::to_string(e) + ": prims_per_object is limited to 16");
+            BvhBuilder builder(nodes, slots, 32, leaf_objects, q.prims_per_object);
             q.bvh_root = builder.build(objs);
             // the hit record of a BVH member is rebuilt with the entry's transform
             for (uint32_t k = 0; k < w.prim_count; ++k) prims[w.first_prim + k].instance = w.instance;
@@ -421,6 +424,10 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
         }
         entries[e] = q;
     }
+    // leaf records of the hierarchies, in tree order (a leaf reference holds a 27-bit record index)
+    if (slots.size() >= (1u << 27) - 1u) return bad("too many hierarchy members");
+    std::vector<DevScanRec> leaves(slots.size());
+    for (size_t i = 0; i < slots.size(); ++i) leaves[i] = scan_record(slots[i]);
     // ---- images
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -460,7 +467,7 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     if ((rc = upload(c, perlins, &s.perlins))) return rc;
     if ((rc = upload(c, insts, &s.instances))) return rc;
     if ((rc = upload(c, nodes, &s.bvh_nodes))) return rc;
-    if ((rc = upload(c, slots, &s.bvh_objects))) return rc;
+    if ((rc = upload(c, leaves, &s.bvh_leaves))) return rc;
     s.n_prims = d->n_prims;
     s.n_entries = d->n_world;
     s.n_lights = d->n_lights;
