@@ -33,9 +33,11 @@ class BvhBuilder {
         uint32_t idx = (uint32_t)nodes_.size();
         DevBvhNode nd{};
         set_child(nd, 0, r);
-        nd.c1 = 0xffffffffu;
-        nd.n1 = 0;
-        for (int a = 0; a < 3; ++a) { nd.lo1[a] = INFINITY; nd.hi1[a] = -INFINITY; }
+        Ref none;
+        none.c = 0x7ffffffu;  // with n = 16 the reference is 0xffffffff, "no reference"
+        none.n = 16;
+        for (int a = 0; a < 3; ++a) { none.lo[a] = INFINITY; none.hi[a] = -INFINITY; }
+        set_child(nd, 1, none);
         nodes_.push_back(nd);
         return idx;
     }
@@ -52,11 +54,16 @@ class BvhBuilder {
     uint32_t ppo_;
 
     static void set_child(DevBvhNode& nd, int which, const Ref& r) {
-        float* lo = which ? nd.lo1 : nd.lo0;
-        float* hi = which ? nd.hi1 : nd.hi0;
-        for (int a = 0; a < 3; ++a) { lo[a] = r.lo[a]; hi[a] = r.hi[a]; }
-        (which ? nd.c1 : nd.c0) = r.c;
-        (which ? nd.n1 : nd.n0) = r.n;
+        const uint32_t ref = r.n ? (0x80000000u | ((r.n - 1u) << 27) | r.c) : r.c;
+        if (which == 0) {
+            nd.lo0x = r.lo[0]; nd.lo0y = r.lo[1]; nd.lo0z = r.lo[2];
+            nd.hi0x = r.hi[0]; nd.hi0y = r.hi[1]; nd.hi0z = r.hi[2];
+            nd.ref0 = ref;
+        } else {
+            nd.lo1x = r.lo[0]; nd.lo1y = r.lo[1]; nd.lo1z = r.lo[2];
+            nd.hi1x = r.hi[0]; nd.hi1y = r.hi[1]; nd.hi1z = r.hi[2];
+            nd.ref1 = ref;
+        }
     }
     static float area(const float* lo, const float* hi) {
         float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];

@@ -402,80 +402,74 @@ constexpr uint32_t kWalkIdle = 0xffffffffu;   // no reference: the walk is over
 constexpr uint32_t kRefLeaf = 0x80000000u;    // leaf reference: bit 31, (records - 1) << 27, first record
 constexpr uint32_t kRefLeafIndexMask = (1u << 27) - 1u;
 
-MIRT_DEV uint32_t child_ref(uint32_t c, uint32_t n) { return n ? (kRefLeaf | ((n - 1u) << 27) | c) : c; }
 MIRT_DEV bool ref_is_leaf(uint32_t ref) { return ref != kWalkIdle && (ref & kRefLeaf); }
 MIRT_DEV bool ref_is_node(uint32_t ref) { return !(ref & kRefLeaf); }
 
-MIRT_DEV bool slab(const float* lo, const float* hi, V3 o, V3 inv_d, float t_min, float t_max, float& t_near) {
-    float tx0 = (lo[0] - o.x) * inv_d.x, tx1 = (hi[0] - o.x) * inv_d.x;
-    float ty0 = (lo[1] - o.y) * inv_d.y, ty1 = (hi[1] - o.y) * inv_d.y;
-    float tz0 = (lo[2] - o.z) * inv_d.z, tz1 = (hi[2] - o.z) * inv_d.z;
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), t_min));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), t_max));
-    t_near = tn;
-    return tn <= tf * 1.0000004f;
-}
+// Two floats in a register pair: + - * on them are single packed instructions (v_pk_add_f32, v_pk_mul_f32).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Walk {
-    LRay lr;         // the ray in the frame of the entry being walked
+    LRay lr;         // the ray in the frame of the hierarchy being walked
     uint32_t ref;    // current reference (interior node index or leaf run) or kWalkIdle
     uint32_t sp;     // entries on this lane's stack
-    uint32_t entry;  // world entry being walked
+    uint32_t next;   // how many of the scene's hierarchies this ray has started
     float closest;   // t of the closest hit so far (starts at the list scans' result)
     int best;        // its primitive, -1 = none
 };
 
-// Start the walk of the first hierarchy entry at index >= w.entry, or go idle when there is none.
-// A ray with a NaN component hits no primitive (see sphere_hit_c) but would pass every box test
-// (min / max drop NaN operands) and visit the whole tree: it goes idle at once.
-template <uint32_t F>
-MIRT_DEV void walk_next_entry(const DevScene& s, const Ray& r, Walk& w) {
-    w.ref = kWalkIdle;
-    w.sp = 0;
+// Number of hierarchies the ray has to walk. A ray with a NaN component hits no primitive (see
+// sphere_hit_c) but would pass every box test (min / max drop NaN operands) and visit whole trees: it
+// walks none.
+MIRT_DEV uint32_t walk_count(const DevScene& s, const Ray& r) {
     const float nan_probe = (r.o.x + r.o.y + r.o.z) + (r.d.x + r.d.y + r.d.z);
-    if (nan_probe != nan_probe) return;
-    for (uint32_t e = w.entry; e < s.n_entries; ++e) {
-        const DevEntry& en = s.entries[e];
-        if (en.kind != EK_BVH) continue;
-        w.entry = e;
-        // 1-ulp reciprocals; slab() widens the far bound by more than that
-        w.lr = make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
-        w.ref = en.bvh_root;
-        return;
-    }
+    return nan_probe != nan_probe ? 0u : s.n_bvh_entries;
 }
 
-// The walk ran out of references in its entry: pop, or move on to the next hierarchy entry.
+// Start the walk of the scene's hierarchy number w.next (world order) and count it as started.
 template <uint32_t F>
-MIRT_DEV void walk_pop(const DevScene& s, const Ray& r, Walk& w, const uint32_t* stack, uint32_t stride) {
-    if (w.sp) {
-        w.ref = stack[(--w.sp) * stride];
-    } else {
-        ++w.entry;
-        walk_next_entry<F>(s, r, w);
-    }
+MIRT_DEV void walk_begin(const DevScene& s, const Ray& r, Walk& w) {
+    const DevEntry& en = s.entries[s.bvh_entries[w.next++]];
+    // 1-ulp reciprocals; slab() widens the far bound by more than that
+    w.lr = make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
+    w.ref = en.bvh_root;
+    w.sp = 0;
+}
+
+// Next reference from the lane's stack; idle when the hierarchy is exhausted.
+MIRT_DEV void walk_pop(Walk& w, const uint32_t* stack, uint32_t stride) {
+    w.ref = kWalkIdle;
+    if (w.sp) w.ref = stack[(--w.sp) * stride];
 }
 
 // BVHNode::hit (aabb.rs:112-126) for one interior node: test both child boxes against [t_min,
-// closest], continue with the nearer hit child and push the other. `stack` is this lane's column of
-// an LDS array laid out [level][lane] (stride = blockDim.x words): pushes and pops are conflict-free.
-template <uint32_t F>
-MIRT_DEV void walk_node(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t* stack, uint32_t stride) {
-    const DevBvhNode& nd = s.bvh_nodes[w.ref];
-    float tn0, tn1;
-    const bool h0 = slab(nd.lo0, nd.hi0, w.lr.r.o, w.lr.rinv, t_min, w.closest, tn0);
-    const bool h1 = nd.c1 != 0xffffffffu && slab(nd.lo1, nd.hi1, w.lr.r.o, w.lr.rinv, t_min, w.closest, tn1);
-    const uint32_t r0 = child_ref(nd.c0, nd.n0), r1 = child_ref(nd.c1, nd.n1);
-    if (h0 && h1) {
+// closest] (the slab test of aabb.rs:43-60 with the far bound widened by 4 ulp, which covers the 1-ulp
+// reciprocals), continue with the nearer hit child and push the other. The twelve plane distances are
+// six packed subtract / multiply pairs. `stack` is this lane's column of an LDS array laid out
+// [level][lane] (stride = blockDim.x words): pushes and pops are conflict-free.
+MIRT_DEV void walk_node(const DevScene& s, float t_min, Walk& w, uint32_t* stack, uint32_t stride) {
+    const float4* q = reinterpret_cast<const float4*>(s.bvh_nodes + w.ref);
+    const float4 a = q[0], b = q[1], c = q[2];
+    const uint4 refs = reinterpret_cast<const uint4*>(q)[3];
+    const f32x2 oxy = {w.lr.r.o.x, w.lr.r.o.y}, ozz = {w.lr.r.o.z, w.lr.r.o.z};
+    const f32x2 rxy = {w.lr.rinv.x, w.lr.rinv.y}, rzz = {w.lr.rinv.z, w.lr.rinv.z};
+    const f32x2 l0 = (f32x2{a.x, a.y} - oxy) * rxy, h0 = (f32x2{a.z, a.w} - oxy) * rxy;
+    const f32x2 l1 = (f32x2{b.x, b.y} - oxy) * rxy, h1 = (f32x2{b.z, b.w} - oxy) * rxy;
+    const f32x2 z0 = (f32x2{c.x, c.y} - ozz) * rzz, z1 = (f32x2{c.z, c.w} - ozz) * rzz;
+    const float tn0 = fmaxf(fmaxf(fminf(l0.x, h0.x), fminf(l0.y, h0.y)), fmaxf(fminf(z0.x, z0.y), t_min));
+    const float tf0 = fminf(fminf(fmaxf(l0.x, h0.x), fmaxf(l0.y, h0.y)), fminf(fmaxf(z0.x, z0.y), w.closest));
+    const float tn1 = fmaxf(fmaxf(fminf(l1.x, h1.x), fminf(l1.y, h1.y)), fmaxf(fminf(z1.x, z1.y), t_min));
+    const float tf1 = fminf(fminf(fmaxf(l1.x, h1.x), fmaxf(l1.y, h1.y)), fminf(fmaxf(z1.x, z1.y), w.closest));
+    const bool hit0 = tn0 <= tf0 * 1.0000004f, hit1 = tn1 <= tf1 * 1.0000004f;
+    if (hit0 && hit1) {
         const bool first0 = tn0 <= tn1;
-        w.ref = first0 ? r0 : r1;
-        if (w.sp < (uint32_t)kBvhStackDepth) stack[(w.sp++) * stride] = first0 ? r1 : r0;
-    } else if (h0) {
-        w.ref = r0;
-    } else if (h1) {
-        w.ref = r1;
+        w.ref = first0 ? refs.x : refs.y;
+        if (w.sp < (uint32_t)kBvhStackDepth) stack[(w.sp++) * stride] = first0 ? refs.y : refs.x;
+    } else if (hit0) {
+        w.ref = refs.x;
+    } else if (hit1) {
+        w.ref = refs.y;
     } else {
-        walk_pop<F>(s, r, w, stack, stride);
+        walk_pop(w, stack, stride);
     }
 }
 
@@ -504,7 +498,7 @@ MIRT_DEV bool leaf_rec_hit(const DevScene& s, const DevScanRec& rec, const LRay&
 
 // The records of one leaf, in object order (a later record wins a tie, as in ray.rs:123-133).
 template <uint32_t F>
-MIRT_DEV void walk_leaf(const DevScene& s, const Ray& r, float t_min, Walk& w, const uint32_t* stack, uint32_t stride) {
+MIRT_DEV void walk_leaf(const DevScene& s, float t_min, Walk& w, const uint32_t* stack, uint32_t stride) {
     const uint32_t first = w.ref & kRefLeafIndexMask, n = ((w.ref >> 27) & 15u) + 1u;
     for (uint32_t j = 0; j < n; ++j) {
         const DevScanRec& rec = s.bvh_leaves[first + j];
@@ -514,15 +508,24 @@ MIRT_DEV void walk_leaf(const DevScene& s, const Ray& r, float t_min, Walk& w, c
             w.best = (int)rec.prim;
         }
     }
-    walk_pop<F>(s, r, w, stack, stride);
+    walk_pop(w, stack, stride);
 }
 
-// Walk every hierarchy entry to the end.
+// Walk every hierarchy of the scene to the end.
 template <uint32_t F>
 MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t* stack, uint32_t stride) {
-    while (w.ref != kWalkIdle) {
-        if (ref_is_node(w.ref)) walk_node<F>(s, r, t_min, w, stack, stride);
-        else walk_leaf<F>(s, r, t_min, w, stack, stride);
+    const uint32_t n = walk_count(s, r);
+    w.next = 0;
+    w.ref = kWalkIdle;
+    while (w.next < n) {
+        walk_begin<F>(s, r, w);
+        // Two nested loops rather than one step of either kind per iteration: the lanes of a wave
+        // descend through interior nodes until each of them holds a leaf (or is done), then all
+        // intersect their leaves together, so the long leaf code runs with many lanes active.
+        while (w.ref != kWalkIdle) {
+            while (ref_is_node(w.ref)) walk_node(s, t_min, w, stack, stride);
+            if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, w, stack, stride);
+        }
     }
 }
 
@@ -547,10 +550,8 @@ MIRT_DEV void world_hit(const DevScene& s, const Ray& r, const DrawKey& key, uin
     world_lists<F>(s, r, key, closest, best);
     if (F & F_BVH) {
         Walk w;
-        w.entry = 0;
         w.closest = closest;
         w.best = best;
-        walk_next_entry<F>(s, r, w);
         walk_run<F>(s, r, 0.001f, w, stack, stride);
         closest = w.closest;
         best = w.best;

@@ -86,18 +86,17 @@ struct __attribute__((aligned(16))) DevEntry {
     uint32_t scan_count;
 };
 
-// 64-byte node holding the boxes of both children, so one interior step is one 64-byte fetch.
-// Child i: n_i == 0 -> interior node index c_i; n_i > 0 -> leaf of n_i primitive records (at most 16)
-// starting at record c_i of bvh_leaves. c1 == 0xffffffff marks a missing second child (single-leaf tree).
+// 64-byte node holding the boxes of both children, so one interior step is one 64-byte fetch (four
+// 16-byte loads). The box coordinates are grouped in the pairs the slab test consumes with packed
+// two-float arithmetic: (x, y) of each corner, and (lo.z, hi.z) of each box.
+// ref_i is the reference a walk continues with when it enters child i: an interior node index, or
+// bit 31 | (records - 1) << 27 | first record for a leaf of up to 16 primitive records in bvh_leaves.
+// A missing second child (single-leaf tree) has an empty box (lo = +inf, hi = -inf).
 struct __attribute__((aligned(16))) DevBvhNode {
-    float lo0[3];
-    uint32_t c0;
-    float hi0[3];
-    uint32_t n0;
-    float lo1[3];
-    uint32_t c1;
-    float hi1[3];
-    uint32_t n1;
+    float lo0x, lo0y, hi0x, hi0y;
+    float lo1x, lo1y, hi1x, hi1y;
+    float lo0z, hi0z, lo1z, hi1z;
+    uint32_t ref0, ref1, pad0, pad1;
 };
 static_assert(sizeof(DevBvhNode) == 64, "DevBvhNode is four 16-byte quads");
 
@@ -129,6 +128,8 @@ struct DevScene {
     const DevInstance* instances;
     const DevBvhNode* bvh_nodes;
     const DevScanRec* bvh_leaves;  // leaf primitive records in tree order (same record form as the list scans)
+    const uint32_t* bvh_entries;   // indices into entries of the EK_BVH ones, in world order
+    uint32_t n_bvh_entries;
     uint32_t n_prims, n_entries, n_lights, n_media;
     uint32_t n_instances, n_textures;
     uint32_t features;

@@ -17,6 +17,8 @@
 
 using namespace mirt;
 
+constexpr int kCounters = 8;
+
 struct mirt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -32,7 +34,7 @@ struct mirt_ctx {
     uint32_t width = 0, height = 0;
     uint8_t* frame_dev = nullptr;
     size_t frame_dev_bytes = 0;
-    unsigned long long* seg_counter = nullptr;
+    unsigned long long* seg_counter = nullptr;  // kCounters device counters: segments, lane slots, walk[6]
     mirt_stats stats{};
     // wavefront kernel set: path state + queues for `wf_capacity` slots, counters mirrored in pinned memory
     WfState wf{};
@@ -152,8 +154,8 @@ int mirt_create(int device, mirt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(c->seg_counter, 0, 2 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), kCounters * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->seg_counter, 0, kCounters * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     *out = c;
     return MIRT_OK;
 }
@@ -468,6 +470,11 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     if ((rc = upload(c, insts, &s.instances))) return rc;
     if ((rc = upload(c, nodes, &s.bvh_nodes))) return rc;
     if ((rc = upload(c, leaves, &s.bvh_leaves))) return rc;
+    std::vector<uint32_t> bvh_entries;
+    for (uint32_t e = 0; e < d->n_world; ++e)
+        if (entries[e].kind == EK_BVH) bvh_entries.push_back(e);
+    if ((rc = upload(c, bvh_entries, &s.bvh_entries))) return rc;
+    s.n_bvh_entries = (uint32_t)bvh_entries.size();
     s.n_prims = d->n_prims;
     s.n_entries = d->n_world;
     s.n_lights = d->n_lights;
@@ -518,7 +525,7 @@ int mirt_frame_begin(mirt_ctx* c, uint32_t width, uint32_t height, float* accum_
     c->width = width;
     c->height = height;
     HIP_TRY(c, hipMemsetAsync(c->accum, 0, pixels * sizeof(float4), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->seg_counter, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->seg_counter, 0, kCounters * sizeof(unsigned long long), c->stream));
     c->stats = mirt_stats{};
     return MIRT_OK;
 }
@@ -776,10 +783,11 @@ int mirt_get_stats(mirt_ctx* c, mirt_stats* out) {
     if (!c || !out) return MIRT_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long seg[2] = {0, 0};
+    unsigned long long seg[kCounters] = {};
     HIP_TRY(c, hipMemcpy(seg, c->seg_counter, sizeof(seg), hipMemcpyDeviceToHost));
     c->stats.segments = seg[0];
     c->stats.lane_slots = seg[1];
+    for (int i = 0; i < 6; ++i) c->stats.walk[i] = seg[2 + i];
     if (c->stats.kernel_launches) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.kernel_ms = ms;

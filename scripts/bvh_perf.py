@@ -1,0 +1,29 @@
+"""Throughput of the hierarchy scenes (random, final, random with num=500) with the fused kernel set.
+MIRT_LIB selects the library build, so variants can be compared by running this once per build."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ray_tracing_amd as rt
+
+out = [os.path.basename(rt.LIB_PATH)]
+for scene, spp, depth, (W, H), kw in [("random", 32, 50, (1920, 1080), {}), ("final", 16, 50, (1920, 1080), {}),
+                                      ("random", 2, 10, (3840, 2160), {"random_num": 500})]:
+    sc = rt.select_scene(scene, **kw)
+    ctx = rt.Context(0)
+    ctx.scene_upload(sc)
+    ctx.camera_set(rt.Camera.select_camera(W / H, scene))
+    best = 0.0
+    for rep in range(2):
+        ctx.frame_begin(W, H)
+        ctx.render(spp, depth, seed=rep, kernel=rt.KERNEL_FUSED)
+        ctx.synchronize()
+        st = ctx.stats()
+        best = max(best, st["samples"] / st["kernel_ms"] / 1e3)
+    wk = st["walk"]
+    seg = max(st["segments"], 1)
+    extra = ""
+    if wk[0]:
+        extra = (f"; per segment: {wk[1] / seg:.1f} node visits, {wk[3] / seg:.1f} leaves; lanes/step: node {wk[1] / wk[0]:.1f}, "
+                 f"leaf {wk[3] / max(wk[2], 1):.1f}, shade {wk[5] / max(wk[4], 1):.1f}; wave steps per wave-segment: node {wk[0] * 64 / seg:.1f}, "
+                 f"leaf {wk[2] * 64 / seg:.1f}, rounds {wk[4] * 64 / seg:.2f}")
+    out.append(f"{scene}{'-1M' if kw else ''} {best:8.1f} Msamples/s ({st['segments'] / st['kernel_ms'] / 1e6:.2f} Gseg/s{extra})")
+print("\n   ".join(out), flush=True)

@@ -19,7 +19,7 @@ import csv, glob, collections
 tot = collections.defaultdict(float)
 for f in glob.glob("$OUT/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "render_fused" in r["Kernel_Name"] or "wavefront" in r["Kernel_Name"] or "extend" in r["Kernel_Name"] or "shade" in r["Kernel_Name"]:
+        if "render_" in r["Kernel_Name"] or "wavefront" in r["Kernel_Name"] or "extend" in r["Kernel_Name"] or "shade" in r["Kernel_Name"]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"])
 for k in sorted(tot): print(k, tot[k])
 PY
