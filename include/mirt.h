@@ -155,9 +155,7 @@ typedef struct mirt_stats {
     uint32_t kernel_used;  /* MIRT_KERNEL_FUSED or MIRT_KERNEL_WAVEFRONT */
     uint64_t lane_slots;   /* fused kernel: 64 x loop iterations summed over waves; segments / lane_slots =
                               share of lane-iterations that traced a segment (the rest idled in a wave whose
-                              other lanes had longer paths); walk kernel: 64 x shading rounds */
-    uint64_t walk[6];      /* kernel for hierarchy scenes: node steps, lanes active in them, leaf steps, lanes
-                              active in them, shading rounds, lanes shaded (0 for the other kernels) */
+                              other lanes had longer paths) */
 } mirt_stats;
 
 /* ---- entry points --------------------------------------------------------------------------- */

@@ -47,8 +47,7 @@ class mirt_render_params(C.Structure):
 
 class mirt_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("kernel_ms", C.c_double),
-                ("kernel_launches", C.c_uint32), ("kernel_used", C.c_uint32), ("lane_slots", C.c_uint64),
-                ("walk", C.c_uint64 * 6)]
+                ("kernel_launches", C.c_uint32), ("kernel_used", C.c_uint32), ("lane_slots", C.c_uint64)]
 
 
 class mirt_prim(C.Structure):
@@ -322,8 +321,7 @@ class Context:
         s = mirt_stats()
         self._check(lib().mirt_get_stats(self._c, C.byref(s)))
         return {"samples": s.samples, "segments": s.segments, "kernel_ms": s.kernel_ms,
-                "kernel_launches": s.kernel_launches, "kernel_used": s.kernel_used, "lane_slots": s.lane_slots,
-                "walk": list(s.walk)}
+                "kernel_launches": s.kernel_launches, "kernel_used": s.kernel_used, "lane_slots": s.lane_slots}
 
 
 class Renderer:

@@ -392,10 +392,11 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
 // leaves as runs of 32-byte primitive records, per-lane traversal stack in LDS.
 //
 // Traversal is written as a resumable walk: `Walk` holds everything a lane needs to continue
-// (local ray, current reference, stack depth, entry, closest hit so far), walk_node() consumes one
-// interior reference and walk_leaf() one leaf reference. A caller that only wants the answer loops
-// until the walk is idle (walk_run); the render kernel for hierarchy scenes interleaves the steps of
-// its 64 lanes with shading so that lanes whose walk ended early do not wait for the longest one.
+// (local ray, current reference, stack depth, hierarchies started, closest hit so far), walk_node()
+// consumes one interior reference and walk_leaf() one leaf reference; walk_run() loops until the
+// walk is idle. (Interleaving the walk steps of a wave's lanes with shading rounds, so that lanes
+// whose walk ended early need not wait for the longest one, was measured and lost 5-20 %: a shading
+// round costs as much as ~25 node steps, and every extra round runs that code again.)
 // ---------------------------------------------------------------------------------------------
 constexpr int kBvhStackDepth = 32;
 constexpr uint32_t kWalkIdle = 0xffffffffu;   // no reference: the walk is over

@@ -9,7 +9,6 @@
 //   first_hit_kernel     world.hit(ray, 0.001, inf) for explicit rays (deterministic check).
 //   ray_color_kernel     one un-sanitised radiance sample per explicit ray.
 //   resolve_kernel       mean, clamp, sqrt, *256 -> RGBA8 with the row flip (renderer.rs:97,109-116).
-#include <cstdlib>
 #include "kernels.h"
 #include "dev_core.h"
 
@@ -110,7 +109,7 @@ __device__ __forceinline__ void shade_segment(const RenderArgs& a, const Tables&
 }
 
 // Adds the lane's sample sums to the accumulation buffer and the wave's counters to the statistics:
-// one atomic per wave for the segment count, one for 64 x `rounds` (the wave's shading rounds).
+// one atomic per wave for the segment count, one for 64 x `rounds` (the wave's loop iterations).
 __device__ __forceinline__ void finish_pixel(const RenderArgs& a, bool valid, uint32_t pixel, V3 acc, uint32_t segments, uint32_t rounds) {
     if (valid) {
         float4 v = a.accum[pixel];
@@ -179,116 +178,6 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(Rend
         shade_segment<F, PINHOLE>(a, tb, pixel, x, y, jitter, sample_end, t, prim, ray, thr, acc, sample, depth_left, bounce, alive);
     }
     finish_pixel(a, valid, pixel, acc, segments, segments);
-}
-
-// The sample loop for scenes with hierarchies. A hierarchy walk takes a different number of steps for
-// every ray, so in the loop above the lanes of a wave would all wait for the longest walk of each
-// segment. Here every lane carries a resumable walk (dev_core.h `Walk`) and the wave alternates between
-//   * walk steps: all lanes at an interior node test it; lanes holding a leaf wait until kLeafBatch of
-//     them do (or no lane is at a node) and then intersect their leaves together; lanes between two
-//     hierarchies of the scene start the next one once kBeginBatch of them wait for that;
-//   * a shading round, once at least kShadeNum/kShadeDen of the live lanes have finished their trace
-//     (or none is walking): those lanes shade, scatter or start their next sample and scan the world's
-//     lists for the new ray, while the others keep their walk state.
-// Draws are addressed by (pixel, sample, bounce), so the samples are those of the loop above.
-#ifndef MIRT_SHADE_NUM
-#define MIRT_SHADE_NUM 1
-#endif
-#ifndef MIRT_SHADE_DEN
-#define MIRT_SHADE_DEN 2
-#endif
-#ifndef MIRT_LEAF_BATCH
-#define MIRT_LEAF_BATCH 16
-#endif
-#ifndef MIRT_BEGIN_BATCH
-#define MIRT_BEGIN_BATCH 16
-#endif
-constexpr uint32_t kShadeNum = MIRT_SHADE_NUM, kShadeDen = MIRT_SHADE_DEN, kLeafBatch = MIRT_LEAF_BATCH, kBeginBatch = MIRT_BEGIN_BATCH;
-
-template <uint32_t F, bool PINHOLE>
-__global__ __launch_bounds__(kBlock, waves_for(F)) void render_walk_kernel(RenderArgs a) {
-    __shared__ uint32_t bvh_stack[kBvhStackDepth * kBlock];
-    uint32_t* stack = bvh_stack + threadIdx.x;
-    const Tables tb{a.scene.prims, a.scene.shade, a.scene.instances, a.scene.light_prims};
-
-    uint32_t x, y;
-    thread_pixel(a.width, x, y);
-    const bool valid = x < a.width && y < a.height;
-    const uint32_t pixel = y * a.width + x;
-    const bool jitter = a.jitter != 0;
-
-    V3 acc = v3(0.f, 0.f, 0.f);
-    uint32_t segments = 0, rounds = 0;
-    uint32_t ws[6] = {0, 0, 0, 0, 0, 0};
-    uint32_t sample = a.spp_begin;
-    const uint32_t sample_end = a.spp_begin + a.spp_count;
-    bool alive = valid && a.max_depth > 0 && sample < sample_end;
-    uint32_t depth_left = a.max_depth, bounce = 0;
-    Ray ray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f), 0.f};
-    V3 thr = v3(1.f, 1.f, 1.f);
-    Walk w;
-    w.lr = make_lray(ray);
-    w.ref = kWalkIdle;
-    w.sp = 0;
-    w.next = 0;
-    w.closest = MIRT_INF;
-    w.best = -1;
-    uint32_t n_walks = 0;  // hierarchies the current ray has to walk
-    bool fresh = alive;    // the lane has a new ray whose trace has not begun
-    if (alive) {
-        Rng g;
-        g.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
-        ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, g);
-    }
-    for (;;) {
-        // ---- new rays: scene.world.hit (renderer.rs:201) starts with the world's lists; the hierarchies
-        //      the ray has to walk are begun by the step loop below
-        if (fresh) {
-            DrawKey key{pixel, sample, bounce, a.seed};
-            w.closest = MIRT_INF;
-            w.best = -1;
-            world_lists<F>(a.scene, ray, key, w.closest, w.best);
-            w.next = 0;
-            n_walks = walk_count(a.scene, ray);
-            ++segments;
-            fresh = false;
-        }
-        // ---- walk steps until enough lanes wait for shading. One kind of step per iteration: begin the
-        //      next hierarchy (lanes between hierarchies), intersect leaves, or test interior nodes.
-        for (;;) {
-            const bool at_node = w.ref != kWalkIdle && ref_is_node(w.ref);
-            const bool at_leaf = ref_is_leaf(w.ref);
-            const bool pending = alive && w.ref == kWalkIdle && w.next < n_walks;
-            const uint32_t n_alive = __popcll(__ballot(alive));
-            const uint32_t n_node = __popcll(__ballot(at_node)), n_leaf = __popcll(__ballot(at_leaf));
-            const uint32_t n_pending = __popcll(__ballot(pending));
-            const uint32_t n_busy = n_node + n_leaf + n_pending;
-            if (n_busy == 0 || (n_alive - n_busy) * kShadeDen >= n_alive * kShadeNum) break;
-            if (n_pending >= kBeginBatch || n_node + n_leaf == 0) {
-                if (pending) walk_begin<F>(a.scene, ray, w);
-            } else if (n_leaf >= kLeafBatch || n_node == 0) {
-                ws[2] += 1; ws[3] += n_leaf;
-                if (at_leaf) walk_leaf<F>(a.scene, 0.001f, w, stack, kBlock);
-            } else {
-                ws[0] += 1; ws[1] += n_node;
-                if (at_node) walk_node(a.scene, 0.001f, w, stack, kBlock);
-            }
-        }
-        if (__ballot(alive) == 0) break;
-        // ---- a shading round for the lanes whose trace is complete
-        ++rounds;
-        const bool shade = alive && w.ref == kWalkIdle && w.next >= n_walks;
-        ws[4] += 1; ws[5] += __popcll(__ballot(shade));
-        if (shade) {
-            shade_segment<F, PINHOLE>(a, tb, pixel, x, y, jitter, sample_end, w.closest, w.best, ray, thr, acc, sample, depth_left, bounce,
-                                      alive);
-            fresh = alive;
-        }
-    }
-    finish_pixel(a, valid, pixel, acc, segments, rounds);
-    // wave-uniform step statistics: steps taken and lanes active in them
-    if ((threadIdx.x & 63u) == 0 && a.segment_counter)
-        for (int i = 0; i < 6; ++i) atomicAdd(a.segment_counter + 2 + i, (unsigned long long)ws[i]);
 }
 
 template <uint32_t F>
@@ -402,15 +291,6 @@ struct RenderLauncher {
         const bool lds = s.n_prims <= kLdsPrims && s.n_instances <= kLdsInstances && s.n_lights <= kLdsLights;
         const bool pinhole = a.cam.lens_radius == 0.f && !(s.features & F_MOVING);
         dim3 grid(tiles), block(kBlock);
-        if constexpr ((F & F_BVH) != 0) {
-            // hierarchy scenes: the interleaved walk / shade loop (MIRT_WALK=0 keeps the lock-step loop for A/B runs)
-            static const bool walk = [] { const char* e = std::getenv("MIRT_WALK"); return e && e[0] == '1'; }();
-            if ((s.features & F_BVH) && walk) {
-                if (pinhole) hipLaunchKernelGGL((render_walk_kernel<F, true>), grid, block, 0, stream, a);
-                else hipLaunchKernelGGL((render_walk_kernel<F, false>), grid, block, 0, stream, a);
-                return hipGetLastError();
-            }
-        }
         if (lds && pinhole) hipLaunchKernelGGL((render_fused_kernel<F, true, true>), grid, block, 0, stream, a);
         else if (lds) hipLaunchKernelGGL((render_fused_kernel<F, true, false>), grid, block, 0, stream, a);
         else if (pinhole) hipLaunchKernelGGL((render_fused_kernel<F, false, true>), grid, block, 0, stream, a);

@@ -17,7 +17,7 @@
 
 using namespace mirt;
 
-constexpr int kCounters = 8;
+constexpr int kCounters = 2;
 
 struct mirt_ctx {
     int device = 0;
@@ -34,7 +34,7 @@ struct mirt_ctx {
     uint32_t width = 0, height = 0;
     uint8_t* frame_dev = nullptr;
     size_t frame_dev_bytes = 0;
-    unsigned long long* seg_counter = nullptr;  // kCounters device counters: segments, lane slots, walk[6]
+    unsigned long long* seg_counter = nullptr;  // kCounters device counters: segments, lane slots
     mirt_stats stats{};
     // wavefront kernel set: path state + queues for `wf_capacity` slots, counters mirrored in pinned memory
     WfState wf{};
@@ -787,7 +787,6 @@ int mirt_get_stats(mirt_ctx* c, mirt_stats* out) {
     HIP_TRY(c, hipMemcpy(seg, c->seg_counter, sizeof(seg), hipMemcpyDeviceToHost));
     c->stats.segments = seg[0];
     c->stats.lane_slots = seg[1];
-    for (int i = 0; i < 6; ++i) c->stats.walk[i] = seg[2 + i];
     if (c->stats.kernel_launches) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.kernel_ms = ms;

@@ -18,12 +18,6 @@ for scene, spp, depth, (W, H), kw in [("random", 32, 50, (1920, 1080), {}), ("fi
         ctx.synchronize()
         st = ctx.stats()
         best = max(best, st["samples"] / st["kernel_ms"] / 1e3)
-    wk = st["walk"]
-    seg = max(st["segments"], 1)
-    extra = ""
-    if wk[0]:
-        extra = (f"; per segment: {wk[1] / seg:.1f} node visits, {wk[3] / seg:.1f} leaves; lanes/step: node {wk[1] / wk[0]:.1f}, "
-                 f"leaf {wk[3] / max(wk[2], 1):.1f}, shade {wk[5] / max(wk[4], 1):.1f}; wave steps per wave-segment: node {wk[0] * 64 / seg:.1f}, "
-                 f"leaf {wk[2] * 64 / seg:.1f}, rounds {wk[4] * 64 / seg:.2f}")
+    extra = f", loop occupancy {st['segments'] / max(st['lane_slots'], 1):.2f}"
     out.append(f"{scene}{'-1M' if kw else ''} {best:8.1f} Msamples/s ({st['segments'] / st['kernel_ms'] / 1e6:.2f} Gseg/s{extra})")
 print("\n   ".join(out), flush=True)
