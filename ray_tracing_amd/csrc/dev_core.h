@@ -164,24 +164,17 @@ MIRT_DEV V3 rand_in_unit_disk(Rng& g) {
         return p;
     }
 }
-// rand_gen.rs:80-90 — r2 in [0, 0.9): z >= sqrt(0.1).
-MIRT_DEV V3 random_cosine_direction(float xi1, float xi2) {
-    float r2 = 0.f + (0.9f - 0.f) * xi2;
-    float z = fast_sqrt(1.f - r2);
-    float r2_sq = fast_sqrt(r2);
-    float sn, cs;
-    sincos_2pi(xi1, sn, cs);  // phi = 2*pi*r1
-    return v3(cs * r2_sq, sn * r2_sq, z);
-}
-
 // onb.rs:38-49 / onb.rs:34-36 — u and v are not normalised.
 struct Onb {
     V3 u, v, w;
 };
 MIRT_DEV Onb onb_from_w(V3 w) {
-    V3 a = fabsf(w.x) > 0.9f ? v3(0.f, 1.f, 0.f) : v3(1.f, 0.f, 0.f);
+    // v = w x a with a = (0,1,0) when |w.x| > 0.9, else (1,0,0). The products with a's zeros are written
+    // out: for finite w they only contribute signed zeros that vanish in the sums (a NaN w gives NaN
+    // directions either way).
+    const bool ay = fabsf(w.x) > 0.9f;
     Onb o;
-    o.v = cross(w, a);
+    o.v = v3(ay ? -w.z : 0.f, ay ? 0.f : w.z, ay ? w.x : -w.y);
     o.u = cross(w, o.v);
     o.w = w;
     return o;
@@ -751,9 +744,29 @@ MIRT_DEV float lights_pdf(const DevScene& s, V3 origin, V3 v) {
     return sum * fast_rcp((float)s.n_lights);
 }
 
-// geo.rs:234-242 (rect) and geo.rs:144-149 with geo.rs:77-85 (sphere): two draws each.
+// A direction drawn around an axis: (cos(2 pi u) * rad, sin(2 pi u) * rad, z) in the basis built from
+// `axis` (onb.rs:34-49). Both the cosine lobe (rand_gen.rs:80-90) and the cone towards a sphere
+// (geo.rs:77-85) have this form, so they share the basis construction and the composition.
+struct AxisDraw {
+    V3 axis;
+    float u, rad, z;
+};
+MIRT_DEV V3 axis_draw_direction(const AxisDraw& a) {
+    float sn, cs;
+    sincos_2pi(a.u, sn, cs);
+    return onb_local(onb_from_w(a.axis), v3(cs * a.rad, sn * a.rad, a.z));
+}
+// rand_gen.rs:80-90 around `normal` — r2 in [0, 0.9): z >= sqrt(0.1).
+MIRT_DEV AxisDraw cosine_draw(V3 normal, float xi1, float xi2) {
+    float r2 = 0.f + (0.9f - 0.f) * xi2;
+    return AxisDraw{normal, xi1, fast_sqrt(r2), fast_sqrt(1.f - r2)};
+}
+
+// HittableList::random's member (ray.rs:152-154) for a light primitive, two draws: geo.rs:234-242
+// (rect: a point on it) gives the direction itself and returns false; geo.rs:144-149 with geo.rs:77-85
+// (sphere: a direction inside its cone) returns true and leaves the direction to axis_draw_direction().
 template <uint32_t F>
-MIRT_DEV V3 light_random_one(const DevPrim& p, V3 origin, float xi1, float xi2) {
+MIRT_DEV bool light_draw(const DevPrim& p, V3 origin, float xi1, float xi2, V3& dir, AxisDraw& ad) {
     uint32_t kind = p.meta & PM_KIND_MASK;
     if ((F & F_RECT) && kind == PK_RECT) {
         uint32_t xi, yi, zi;
@@ -762,20 +775,19 @@ MIRT_DEV V3 light_random_one(const DevPrim& p, V3 origin, float xi1, float xi2) 
         float b = p.a[3] + (p.b[0] - p.a[3]) * xi2;
         float k = p.b[1];
         V3 pt = v3(xi == 0 ? a : (yi == 0 ? b : k), xi == 1 ? a : (yi == 1 ? b : k), xi == 2 ? a : (yi == 2 ? b : k));
-        return fast_normalize(pt - origin);
+        dir = fast_normalize(pt - origin);
+        return false;
     }
     if ((F & F_SPHERE) && kind == PK_SPHERE) {
         V3 c0 = v3(p.a[0], p.a[1], p.a[2]);
         V3 direction = c0 - origin;
         float d = norm_squared(direction);
-        Onb uvw = onb_from_w(direction * fast_rsq(d));
         float z = 1.f + xi2 * (fast_sqrt(1.f - p.a[3] * p.a[3] * fast_rcp(d)) - 1.f);
-        float sn, cs;
-        sincos_2pi(xi1, sn, cs);
-        float s1 = fast_sqrt(1.f - z * z);
-        return onb_local(uvw, v3(cs * s1, sn * s1, z));
+        ad = AxisDraw{direction * fast_rsq(d), xi1, fast_sqrt(1.f - z * z), z};
+        return true;
     }
-    return v3(1.f, 0.f, 0.f);  // ray.rs:41-43
+    dir = v3(1.f, 0.f, 0.f);  // ray.rs:41-43
+    return false;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -845,27 +857,27 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, co
     }
     // Lambertian — material.rs:51-61 with the mixture of renderer.rs:207-221
     V3 att = shade_color<F>(s, m, h);
-    Onb uvw = onb_from_w(h.n);
     V3 dir;
     float pdf_val;
     if (s.n_lights == 0) {
         float a = g.next(), b = g.next();
-        dir = onb_local(uvw, random_cosine_direction(a, b));       // pdf.rs:30-32
-        float c = dot(dir, uvw.w);
+        dir = axis_draw_direction(cosine_draw(h.n, a, b));          // pdf.rs:30-32
+        float c = dot(dir, h.n);
         pdf_val = c <= 0.f ? 0.0001f : c * (1.f / kPi);             // pdf.rs:25-28
     } else {
         float sel = g.next();
         float a = g.next(), b = g.next();
-        if (sel < 0.5f) {                                           // pdf.rs:77-83
-            dir = onb_local(uvw, random_cosine_direction(a, b));
-        } else {
+        AxisDraw ad = cosine_draw(h.n, a, b);                       // pdf.rs:77-83: the cosine half ...
+        bool around_axis = true;
+        if (!(sel < 0.5f)) {                                        // ... or a member of the light list
             float c = g.next();
             // ray.rs:152-154: member floor(n * xi)
             uint32_t li = (uint32_t)(0.f + ((float)s.n_lights - 0.f) * a);
             li = min(li, s.n_lights - 1);
-            dir = light_random_one<F>(tb.light_prims[li], h.p, b, c);
+            around_axis = light_draw<F>(tb.light_prims[li], h.p, b, c, dir, ad);
         }
-        float c = dot(dir, uvw.w);
+        if (around_axis) dir = axis_draw_direction(ad);
+        float c = dot(dir, h.n);
         float p0 = c <= 0.f ? 0.0001f : c * (1.f / kPi);
         float p1 = lights_pdf<F>(s, h.p, dir);
         pdf_val = 0.5f * p0 + 0.5f * p1;                            // pdf.rs:73-75
