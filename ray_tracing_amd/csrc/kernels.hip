@@ -20,8 +20,14 @@ constexpr int kBlock = 256;
 #ifndef MIRT_WAVES
 #define MIRT_WAVES 5
 #endif
+#ifndef MIRT_WAVES_BVH
+#define MIRT_WAVES_BVH 4
+#endif
+#ifndef MIRT_WAVES_TEX
+#define MIRT_WAVES_TEX 4
+#endif
 constexpr int waves_for(uint32_t features) {
-    return (features & (F_TEX_NOISE | F_TEX_IMAGE)) ? 3 : ((features & F_BVH) ? 4 : MIRT_WAVES);
+    return (features & (F_TEX_NOISE | F_TEX_IMAGE)) ? MIRT_WAVES_TEX : ((features & F_BVH) ? MIRT_WAVES_BVH : MIRT_WAVES);
 }
 
 // capacity of the per-block LDS copies of the tables shading indexes per lane
