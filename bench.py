@@ -20,7 +20,11 @@ if ROOT not in sys.path:
 
 FLOP_PER_SEGMENT = 400.0       # algorithmic FLOP of one Cornell path segment (12 rect tests x 12 + sphere 30 +
                                # instance transform 15 + diffuse shade with the 2-light mixture pdf 200)
-PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X FP32 vector peak (packed FMA); 78.6 without packed math
+# MI355X FP32 vector peak (spec, packed v_pk_fma_f32): the `peak` of the roofline object. Plain v_fma_f32 code
+# issues at half of it (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s); the render kernel of the
+# list scenes emits no packed arithmetic, so the fraction of that rate is reported beside `frac`.
+PEAK_FP32_VALU_TFLOPS = 157.3
+UNPACKED_FP32_TFLOPS = 78.6
 # HBM bytes of one render launch of the default workload, from rocprofv3 PMC passes
 # (profiles/r1/cornell_1080p_1024spp_v1_hbm_traffic_pmc.txt): 2 x FETCH_SIZE (gfx950 counts half of a wide read)
 # + WRITE_SIZE, in KiB. It is the float4 accumulation buffer read and written once: 2 x 33.2 MB.
@@ -135,6 +139,7 @@ def main():
                        "samples_per_step": samples_per_step, "parallelism": f"spp-range x{world}" + (" + RCCL reduce" if world > 1 else "")},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "frac_of_unpacked_fma_rate": achieved / UNPACKED_FP32_TFLOPS,
                          "traffic": MEASURED_TRAFFIC_BYTES.get((args.scene, W, H, spp)), "traffic_unit": "bytes per launch (PMC, separate run)",
                          "kernel": "render_fused_kernel", "avg_launch_ms": kernel_ms / max(launches, 1),
                          "segments_per_sample": segments / (W * H * spp * args.steps),
