@@ -44,6 +44,9 @@ MIRT_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x
 MIRT_DEV float comp(V3 v, uint32_t i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 // per-component select (a struct-valued ?: makes hipcc index a two-element array in scratch memory)
 MIRT_DEV V3 select(bool c, V3 a, V3 b) { return V3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+// Two floats in a register pair: + - * and fma on them are single packed instructions (v_pk_add_f32,
+// v_pk_mul_f32, v_pk_fma_f32), each half rounded exactly as the scalar operation would be.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // hardware approximations (about 1 ulp) for the shading code
 MIRT_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
@@ -316,20 +319,62 @@ MIRT_DEV bool rect_rec_hit(const float* f, const LRay& l, float t_min, float t_m
     return (t >= t_min) & (t <= t_max) & (x >= f[1]) & (x <= f[2]) & (y >= f[3]) & (y <= f[4]);
 }
 
+// Two consecutive rects of one axis (f = k, lo0, hi0, lo1, hi1, each as the pair a, b): the same
+// operations as two rect_rec_hit calls, in the same order and with the same roundings, but the plane
+// distances and hit coordinates of both rects come from packed two-float instructions (8 instead of
+// 16). Rect b is tested against the range rect a has already narrowed, as in the sequential scan.
+template <uint32_t XI, uint32_t YI, uint32_t ZI>
+MIRT_DEV void rect_pair_hit(const float* f, uint32_t prim_a, uint32_t prim_b, V3 o, V3 d, V3 rinv, float t_min, float& closest, int& best) {
+    const float oz = comp(o, ZI), dz = comp(d, ZI), rz = comp(rinv, ZI);
+    const float ox = comp(o, XI), dx = comp(d, XI), oy = comp(o, YI), dy = comp(d, YI);
+    const f32x2 n = f32x2{f[0], f[1]} - oz;
+    const f32x2 q = n * rz;
+    const f32x2 e = __builtin_elementwise_fma(-q, (f32x2)dz, n);
+    const f32x2 t = __builtin_elementwise_fma(e, (f32x2)rz, q);  // div_nr on both halves
+    const f32x2 x = ox + t * dx;
+    const f32x2 y = oy + t * dy;
+    const bool ha = (t.x >= t_min) & (t.x <= closest) & (x.x >= f[2]) & (x.x <= f[4]) & (y.x >= f[6]) & (y.x <= f[8]);
+    closest = ha ? t.x : closest;
+    best = ha ? (int)prim_a : best;
+    const bool hb = (t.y >= t_min) & (t.y <= closest) & (x.y >= f[3]) & (x.y <= f[5]) & (y.y >= f[7]) & (y.y <= f[9]);
+    closest = hb ? t.y : closest;
+    best = hb ? (int)prim_b : best;
+}
+
+// The two opposite faces of a cuboid on one axis (geo.rs:253-283: planes k_lo and k_hi with the same
+// extents [lo0, hi0] x [lo1, hi1]); ids prim and prim + 1. Same arithmetic as rect_pair_hit.
+template <uint32_t XI, uint32_t YI, uint32_t ZI>
+MIRT_DEV void face_pair_hit(float k_lo, float k_hi, float lo0, float hi0, float lo1, float hi1, uint32_t prim, V3 o, V3 d, V3 rinv,
+                            float t_min, float& closest, int& best) {
+    const float oz = comp(o, ZI), dz = comp(d, ZI), rz = comp(rinv, ZI);
+    const float ox = comp(o, XI), dx = comp(d, XI), oy = comp(o, YI), dy = comp(d, YI);
+    const f32x2 n = f32x2{k_lo, k_hi} - oz;
+    const f32x2 q = n * rz;
+    const f32x2 e = __builtin_elementwise_fma(-q, (f32x2)dz, n);
+    const f32x2 t = __builtin_elementwise_fma(e, (f32x2)rz, q);
+    const f32x2 x = ox + t * dx;
+    const f32x2 y = oy + t * dy;
+    const bool ha = (t.x >= t_min) & (t.x <= closest) & (x.x >= lo0) & (x.x <= hi0) & (y.x >= lo1) & (y.x <= hi1);
+    closest = ha ? t.x : closest;
+    best = ha ? (int)prim : best;
+    const bool hb = (t.y >= t_min) & (t.y <= closest) & (x.y >= lo0) & (x.y <= hi0) & (y.y >= lo1) & (y.y <= hi1);
+    closest = hb ? t.y : closest;
+    best = hb ? (int)(prim + 1u) : best;
+}
+
 // HittableList::hit (ray.rs:123-133) over the scan records [first, first + count) of a list:
 // primitives are visited in list order and `t <= closest` accepts, so the later primitive wins a
-// tie. Records are wave-uniform: one 32-byte scalar load each, issued one record ahead of its use,
-// and the kind / axis dispatch is a scalar branch.
+// tie. Records are wave-uniform: one 64-byte scalar load each (the other waves of the SIMD cover its
+// latency; holding the next record in registers as well costs more than it hides), and the kind /
+// axis dispatch is a scalar branch.
 template <uint32_t F, bool ALLOW_MEDIUM>
 MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const Ray& r, float t_min, const DrawKey& key,
                         float& closest, int& best) {
     uint32_t cur_inst = 0;
     LRay lr = make_lray(r);
     const DevScanRec* p = s.scan + first;
-    DevScanRec rec = *p;
     for (uint32_t j = 0; j < count; ++j) {
-        ++p;
-        const DevScanRec nxt = *p;  // the array ends with an SC_END record
+        const DevScanRec rec = p[j];
         const uint32_t code = rec.code_inst & 0xffu;
         if (F & F_INSTANCE) {
             const uint32_t inst = rec.code_inst >> 8;
@@ -340,7 +385,10 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
         }
         float t = 0.f;
         bool h = false;
-        if ((F & F_RECT) && code == SC_RECT_XY) h = rect_rec_hit<0, 1, 2>(rec.f, lr, t_min, closest, t);
+        if ((F & F_RECT) && code == SC_RECT2_XY) rect_pair_hit<0, 1, 2>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
+        else if ((F & F_RECT) && code == SC_RECT2_XZ) rect_pair_hit<0, 2, 1>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
+        else if ((F & F_RECT) && code == SC_RECT2_YZ) rect_pair_hit<1, 2, 0>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
+        else if ((F & F_RECT) && code == SC_RECT_XY) h = rect_rec_hit<0, 1, 2>(rec.f, lr, t_min, closest, t);
         else if ((F & F_RECT) && code == SC_RECT_XZ) h = rect_rec_hit<0, 2, 1>(rec.f, lr, t_min, closest, t);
         else if ((F & F_RECT) && code == SC_RECT_YZ) h = rect_rec_hit<1, 2, 0>(rec.f, lr, t_min, closest, t);
         else if ((F & F_SPHERE) && code == SC_SPHERE) h = sphere_hit_c(v3(rec.f), rec.f[3], lr.r, t_min, closest, t);
@@ -352,7 +400,6 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
         }
         closest = h ? t : closest;
         best = h ? (int)rec.prim : best;
-        rec = nxt;
     }
 }
 
@@ -398,9 +445,6 @@ constexpr uint32_t kRefLeafIndexMask = (1u << 27) - 1u;
 
 MIRT_DEV bool ref_is_leaf(uint32_t ref) { return ref != kWalkIdle && (ref & kRefLeaf); }
 MIRT_DEV bool ref_is_node(uint32_t ref) { return !(ref & kRefLeaf); }
-
-// Two floats in a register pair: + - * on them are single packed instructions (v_pk_add_f32, v_pk_mul_f32).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct Walk {
     LRay lr;         // the ray in the frame of the hierarchy being walked
@@ -470,7 +514,7 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, Walk& w, uint32_t* stack
 // One primitive record of a leaf (the record's kind differs from lane to lane, so the rectangle's axes
 // are chosen with per-lane selects). Same tests as the list scan: geo.rs:89-105, geo.rs:196-204.
 template <uint32_t F>
-MIRT_DEV bool leaf_rec_hit(const DevScene& s, const DevScanRec& rec, const LRay& l, float t_min, float t_max, float& t_out) {
+MIRT_DEV bool leaf_rec_hit(const DevScene& s, const DevLeafRec& rec, const LRay& l, float t_min, float t_max, float& t_out) {
     const uint32_t code = rec.code_inst & 0xffu;
     if ((F & F_SPHERE) && (!(F & (F_RECT | F_MOVING)) || code == SC_SPHERE))
         return sphere_hit_c(v3(rec.f), rec.f[3], l.r, t_min, t_max, t_out);
@@ -495,7 +539,16 @@ template <uint32_t F>
 MIRT_DEV void walk_leaf(const DevScene& s, float t_min, Walk& w, const uint32_t* stack, uint32_t stride) {
     const uint32_t first = w.ref & kRefLeafIndexMask, n = ((w.ref >> 27) & 15u) + 1u;
     for (uint32_t j = 0; j < n; ++j) {
-        const DevScanRec& rec = s.bvh_leaves[first + j];
+        const DevLeafRec& rec = s.bvh_leaves[first + j];
+        if ((F & F_RECT) && (rec.code_inst & 0xffu) == SC_CUBOID) {
+            // Cuboid (geo.rs:245-289): its six rects in list order — XY at z lo / hi, XZ at y lo / hi, YZ at
+            // x lo / hi — from the two corners f = (lo.xyz, hi.xyz); ids prim .. prim + 5
+            const float lx = rec.f[0], ly = rec.f[1], lz = rec.f[2], hx = rec.f[3], hy = rec.f[4], hz = rec.f[5];
+            face_pair_hit<0, 1, 2>(lz, hz, lx, hx, ly, hy, rec.prim, w.lr.r.o, w.lr.r.d, w.lr.rinv, t_min, w.closest, w.best);
+            face_pair_hit<0, 2, 1>(ly, hy, lx, hx, lz, hz, rec.prim + 2u, w.lr.r.o, w.lr.r.d, w.lr.rinv, t_min, w.closest, w.best);
+            face_pair_hit<1, 2, 0>(lx, hx, ly, hy, lz, hz, rec.prim + 4u, w.lr.r.o, w.lr.r.d, w.lr.rinv, t_min, w.closest, w.best);
+            continue;
+        }
         float t;
         if (leaf_rec_hit<F>(s, rec, w.lr, t_min, w.closest, t)) {
             w.closest = t;

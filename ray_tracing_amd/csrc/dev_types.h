@@ -29,18 +29,38 @@ struct __attribute__((aligned(16))) DevPrim {
 };
 static_assert(sizeof(DevPrim) == 48, "DevPrim is three 16-byte quads");
 
-// One element of a list scan (32 bytes = one s_load_dwordx8). A list (world entry or the boundary of
-// a medium) is a contiguous range of these in list order; the array ends with one SC_END record so
-// that the scan may always read one record ahead.
+// One primitive of a hierarchy leaf (32 bytes, two 16-byte vector loads per lane).
 //   rect:   f = (k, lo0, hi0, lo1, hi1, -)      sphere: f = (center.xyz, radius, -, -)
-//   moving sphere / medium: data comes from prims[prim]
-enum : uint32_t { SC_SPHERE = 0, SC_RECT_XY = 1, SC_RECT_XZ = 2, SC_RECT_YZ = 3, SC_MEDIUM = 4, SC_SPHERE_MOVING = 5, SC_END = 6 };
-struct __attribute__((aligned(32))) DevScanRec {
+//   moving sphere: data comes from prims[prim]
+enum : uint32_t {
+    SC_SPHERE = 0, SC_RECT_XY = 1, SC_RECT_XZ = 2, SC_RECT_YZ = 3, SC_MEDIUM = 4, SC_SPHERE_MOVING = 5, SC_END = 6,
+    SC_RECT2_XY = 7, SC_RECT2_XZ = 8, SC_RECT2_YZ = 9,  // two consecutive rects of one axis (scan records only)
+    SC_CUBOID = 10,  // the six rects of a cuboid, f = (lo.xyz, hi.xyz), ids prim .. prim + 5 (leaf records only)
+};
+struct __attribute__((aligned(32))) DevLeafRec {
     uint32_t code_inst;  // code | instance << 8
     uint32_t prim;       // index into prims (the id reported for a hit)
     float f[6];
 };
-static_assert(sizeof(DevScanRec) == 32, "DevScanRec is one 32-byte scalar load");
+static_assert(sizeof(DevLeafRec) == 32, "DevLeafRec is two 16-byte loads");
+
+// One element of a list scan (64 bytes = one s_load_dwordx16; the scan index is wave-uniform, so the
+// record stays in scalar registers). A list (world entry or the boundary of a medium) is a contiguous
+// range of these in list order; the array ends with one SC_END record. A record holds one primitive, or
+// two consecutive rects of the same axis and instance
+// (the opposite faces of a cuboid, a pair of walls): their plane distances and hit points are computed
+// with packed two-float arithmetic, so the values of the two rects are interleaved.
+//   rect:       f = (k, lo0, hi0, lo1, hi1)       sphere: f = (center.xyz, radius)
+//   rect pair:  f = (k_a, k_b, lo0_a, lo0_b, hi0_a, hi0_b, lo1_a, lo1_b, hi1_a, hi1_b); ids prim, prim2
+//   moving sphere / medium: data comes from prims[prim]
+struct __attribute__((aligned(64))) DevScanRec {
+    uint32_t code_inst;  // code | instance << 8
+    uint32_t prim;       // index into prims (the id reported for a hit)
+    uint32_t prim2;      // second rect of a pair
+    uint32_t pad;
+    float f[12];
+};
+static_assert(sizeof(DevScanRec) == 64, "DevScanRec is one 64-byte scalar load");
 
 // What shading needs to know about the material of a primitive, resolved at upload so that a hit
 // costs one table read: material kind, its parameter, and — for Metal, or for a texture that is a
@@ -127,7 +147,7 @@ struct DevScene {
     const DevPerlin* perlins;
     const DevInstance* instances;
     const DevBvhNode* bvh_nodes;
-    const DevScanRec* bvh_leaves;  // leaf primitive records in tree order (same record form as the list scans)
+    const DevLeafRec* bvh_leaves;  // leaf primitive records in tree order
     const uint32_t* bvh_entries;   // indices into entries of the EK_BVH ones, in world order
     uint32_t n_bvh_entries;
     uint32_t n_prims, n_entries, n_lights, n_media;

@@ -16,9 +16,10 @@ namespace mirt {
 
 constexpr int kBlock = 256;
 // Waves per SIMD the register allocator is asked to fit (launch bound). Small list-only scenes are
-// VALU-issue bound and gain from 5-6 resident waves; the full-feature kernel needs its registers.
+// VALU-issue bound and gain from 6 resident waves (79 VGPRs, no scratch); the hierarchy and texture
+// variants need their registers.
 #ifndef MIRT_WAVES
-#define MIRT_WAVES 5
+#define MIRT_WAVES 6
 #endif
 #ifndef MIRT_WAVES_BVH
 #define MIRT_WAVES_BVH 4

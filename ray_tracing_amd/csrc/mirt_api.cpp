@@ -89,6 +89,19 @@ void rot_y_host(const mirt_instance& in, const float p[3], float out[3]) {
     out[2] = -in.sin_theta * p[0] + in.cos_theta * p[2];
 }
 
+// True when the six primitives at p are the faces of one Cuboid as geo.rs:253-283 lists them: XY at
+// z lo / hi, XZ at y lo / hi, YZ at x lo / hi, every face spanning the box's extents on its two axes.
+bool is_cuboid(const mirt_prim* p) {
+    static const uint32_t axes[6] = {MIRT_AXIS_XY, MIRT_AXIS_XY, MIRT_AXIS_XZ, MIRT_AXIS_XZ, MIRT_AXIS_YZ, MIRT_AXIS_YZ};
+    for (int i = 0; i < 6; ++i)
+        if (p[i].kind != MIRT_PRIM_RECT || p[i].axis != axes[i] || p[i].instance != p[0].instance) return false;
+    const float lo[3] = {p[4].k, p[2].k, p[0].k}, hi[3] = {p[5].k, p[3].k, p[1].k};
+    static const int first[6] = {0, 0, 0, 0, 1, 1}, second[6] = {1, 1, 2, 2, 2, 2};
+    for (int i = 0; i < 6; ++i)
+        if (p[i].lo[0] != lo[first[i]] || p[i].hi[0] != hi[first[i]] || p[i].lo[1] != lo[second[i]] || p[i].hi[1] != hi[second[i]]) return false;
+    return true;
+}
+
 // Bounding box of one leaf primitive over shutter times [0,1] (geo.rs:116-130, 218-221), in the
 // coordinate frame of its entry (a primitive's own instance applied, geo.rs:340-368, 317-323).
 void prim_bounds(const mirt_prim& p, const mirt_instance* instances, float lo[3], float hi[3]) {
@@ -242,11 +255,12 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
         if (p.flags & MIRT_PRIM_FLIP_FACE) q.meta |= PM_FLIP;
         prims[i] = q;
     }
-    // ---- list-scan records: one 32-byte record per list member, in list order
+    // ---- primitive records: 32 bytes per hierarchy-leaf member; list scans use 64-byte records that hold
+    //      one list member or two consecutive rects of the same axis and instance, in list order
     std::vector<DevScanRec> scan;
     auto scan_record = [&](uint32_t i) {
         const mirt_prim& p = d->prims[i];
-        DevScanRec r{};
+        DevLeafRec r{};
         uint32_t code;
         if (p.kind == MIRT_PRIM_SPHERE) {
             code = (p.flags & MIRT_PRIM_MOVING) ? SC_SPHERE_MOVING : SC_SPHERE;
@@ -264,7 +278,25 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     };
     auto make_scan = [&](uint32_t first, uint32_t count, uint32_t* scan_first, uint32_t* scan_count) {
         *scan_first = (uint32_t)scan.size();
-        for (uint32_t i = first; i < first + count; ++i) scan.push_back(scan_record(i));
+        for (uint32_t i = first; i < first + count; ++i) {
+            const DevLeafRec one = scan_record(i);
+            DevScanRec r{};
+            r.code_inst = one.code_inst;
+            r.prim = i;
+            const mirt_prim& p = d->prims[i];
+            const bool pair = p.kind == MIRT_PRIM_RECT && i + 1 < first + count && d->prims[i + 1].kind == MIRT_PRIM_RECT &&
+                              d->prims[i + 1].axis == p.axis && d->prims[i + 1].instance == p.instance;
+            if (pair) {
+                const DevLeafRec two = scan_record(i + 1);
+                r.code_inst = (SC_RECT2_XY + p.axis) | (p.instance << 8);
+                r.prim2 = i + 1;
+                for (int a = 0; a < 5; ++a) { r.f[2 * a] = one.f[a]; r.f[2 * a + 1] = two.f[a]; }
+                ++i;
+            } else {
+                for (int a = 0; a < 6; ++a) r.f[a] = one.f[a];
+            }
+            scan.push_back(r);
+        }
         *scan_count = (uint32_t)scan.size() - *scan_first;
     };
     if (d->n_instances >= (1u << 24)) return bad("too many instances");
@@ -366,7 +398,8 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     // ---- world entries + BVHs
     std::vector<DevEntry> entries(d->n_world);
     std::vector<DevBvhNode> nodes;
-    std::vector<uint32_t> slots;
+    std::vector<uint32_t> slots;          // first primitive of every leaf record, in tree order
+    std::vector<uint8_t> slot_is_cuboid;  // the record stands for the six rects of a cuboid
     for (uint32_t e = 0; e < d->n_world; ++e) {
         const mirt_entry& w = d->world[e];
         DevEntry q{};
@@ -415,10 +448,16 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
                     for (int a = 0; a < 3; ++a) { o.lo[a] = std::min(o.lo[a], lo[a]); o.hi[a] = std::max(o.hi[a], hi[a]); }
                 }
             }
-            const uint32_t leaf_objects = q.prims_per_object > 1 ? 1u : 2u;
-            if (leaf_objects * q.prims_per_object > 16u) return bad("entry " + std::to_string(e) + ": prims_per_object is limited to 16");
-            BvhBuilder builder(nodes, slots, 32, leaf_objects, q.prims_per_object);
+            // Objects that are cuboids (six rects in the order and with the extents of geo.rs:253-283) become
+            // one leaf record each; other multi-primitive objects keep one record per primitive.
+            bool cuboids = q.prims_per_object == 6;
+            for (uint32_t j = 0; cuboids && j < objs.size(); ++j) cuboids = is_cuboid(d->prims + objs[j].first_prim);
+            const uint32_t records_per_object = cuboids ? 1u : q.prims_per_object;
+            const uint32_t leaf_objects = records_per_object > 1 ? 1u : 2u;
+            if (leaf_objects * records_per_object > 16u) return bad("entry " + std::to_string(e) + ": prims_per_object is limited to 16");
+            BvhBuilder builder(nodes, slots, 32, leaf_objects, records_per_object);
             q.bvh_root = builder.build(objs);
+            slot_is_cuboid.resize(slots.size(), cuboids ? 1 : 0);  // marks the slots this entry added
             // the hit record of a BVH member is rebuilt with the entry's transform
             for (uint32_t k = 0; k < w.prim_count; ++k) prims[w.first_prim + k].instance = w.instance;
         } else {
@@ -428,8 +467,20 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     }
     // leaf records of the hierarchies, in tree order (a leaf reference holds a 27-bit record index)
     if (slots.size() >= (1u << 27) - 1u) return bad("too many hierarchy members");
-    std::vector<DevScanRec> leaves(slots.size());
-    for (size_t i = 0; i < slots.size(); ++i) leaves[i] = scan_record(slots[i]);
+    std::vector<DevLeafRec> leaves(slots.size());
+    for (size_t i = 0; i < slots.size(); ++i) {
+        if (!slot_is_cuboid[i]) {
+            leaves[i] = scan_record(slots[i]);
+            continue;
+        }
+        const mirt_prim* p = d->prims + slots[i];  // XY(z lo), XY(z hi), XZ(y lo), XZ(y hi), YZ(x lo), YZ(x hi)
+        DevLeafRec r{};
+        r.code_inst = SC_CUBOID;
+        r.prim = slots[i];
+        r.f[0] = p[4].k; r.f[1] = p[2].k; r.f[2] = p[0].k;
+        r.f[3] = p[5].k; r.f[4] = p[3].k; r.f[5] = p[1].k;
+        leaves[i] = r;
+    }
     // ---- images
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
