@@ -196,7 +196,8 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     if (d->n_prims && !d->prims) return bad("prims is NULL");
     if (d->n_world && !d->world) return bad("world is NULL");
     if (d->n_lights && !d->lights) return bad("lights is NULL");
-    if (d->n_materials == 0 || !d->materials) return bad("no materials");
+    if (d->n_materials && !d->materials) return bad("materials is NULL");
+    if (d->n_prims && d->n_materials == 0) return bad("no materials");
     if (d->n_textures && !d->textures) return bad("textures is NULL");
     if (d->n_perlins && !d->perlins) return bad("perlins is NULL");
     if (d->n_images && !d->images) return bad("images is NULL");
@@ -676,7 +677,8 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, "mirt_render: sample range overflows 32 bits");
     if (p->kernel > MIRT_KERNEL_WAVEFRONT) return fail(c, MIRT_ERR_INVALID, "mirt_render: unknown kernel selector");
     HIP_TRY(c, hipSetDevice(c->device));
-    if (p->kernel == MIRT_KERNEL_WAVEFRONT) return render_wavefront(c, p);
+    // depth 0 traces nothing (renderer.rs:198-200): the fused kernel just counts the samples
+    if (p->kernel == MIRT_KERNEL_WAVEFRONT && p->max_depth > 0) return render_wavefront(c, p);
     RenderArgs a{};
     a.scene = c->scene;
     a.cam = c->cam;

@@ -401,3 +401,43 @@ def test_first_hit_half_resolution_hierarchy_scenes(rt, oracle, earth, name):
     assert same.mean() > 0.9999, (~same).sum()
     hit = same & (oi >= 0)
     assert (np.abs(ot[hit] - gt[hit]) / np.abs(ot[hit])).max() < 1e-5
+
+
+@pytest.mark.parametrize("w,h", [(37, 19), (8, 8), (33, 9), (2, 2)])
+def test_ragged_frame_sizes(rt, oracle, earth, w, h):
+    """Frames that are not multiples of the 32x8 workgroup tile (and smaller than one tile): every pixel is
+    rendered exactly once per sample, by both kernel sets, and matches the oracle."""
+    orc, ctx, _ = make(rt, oracle, earth, "cornell", w, h)
+    want, _ = orc.render_sums(8, 50, seed=2)
+    for kernel in (rt.KERNEL_FUSED, rt.KERNEL_WAVEFRONT):
+        ctx.frame_begin(w, h)
+        ctx.render(8, 50, seed=2, kernel=kernel)
+        acc = ctx.read_accum()
+        assert acc.shape == (h, w, 4) and (acc[..., 3] == 8).all()
+        assert np.isclose(acc[..., :3], want, rtol=5e-3, atol=2e-3).all(axis=2).mean() > 0.95
+    frame = ctx.resolve_rgba8()
+    assert frame.shape == (h, w, 4) and (frame[..., 3] == 255).all()
+
+
+def test_empty_world_and_zero_samples(rt):
+    """An empty world (scene.rs:290 with no objects) returns the background for every ray; zero samples or
+    zero depth leave the sums untouched (renderer.rs:100, 198-200)."""
+    C = rt.C
+    d = rt.mirt_scene_desc()
+    d.background[0], d.background[1], d.background[2] = 0.25, 0.5, 0.75
+    ctx = rt.Context(0)
+    ctx.scene_upload(d)
+    ctx.camera_set(rt.Camera.select_camera(2.0, "cornell"))
+    ctx.frame_begin(16, 8)
+    ctx.render(3, 5, seed=1)
+    acc = ctx.read_accum()
+    assert np.allclose(acc[..., :3], 3 * np.array([0.25, 0.5, 0.75], dtype=np.float32)) and (acc[..., 3] == 3).all()
+    assert ctx.stats()["segments"] == 16 * 8 * 3
+    ids, t = ctx.first_hit(np.array([[0, 0, 0, 0, 0, 1, 0.5]], dtype=np.float32))
+    assert ids[0] == -1 and np.isinf(t[0])
+    ctx.frame_begin(16, 8)
+    ctx.render(0, 5, seed=1)
+    ctx.render(4, 0, seed=1)            # depth 0: ray_color returns black at once
+    acc = ctx.read_accum()
+    assert (acc[..., :3] == 0).all() and (acc[..., 3] == 4).all()
+    assert C.sizeof(d) > 0
