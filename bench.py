@@ -26,9 +26,9 @@ FLOP_PER_SEGMENT = 400.0       # algorithmic FLOP of one Cornell path segment (1
 PEAK_FP32_VALU_TFLOPS = 157.3
 UNPACKED_FP32_TFLOPS = 78.6
 # HBM bytes of one render launch of the default workload, from rocprofv3 PMC passes
-# (profiles/r1/cornell_1080p_1024spp_v1_hbm_traffic_pmc.txt): 2 x FETCH_SIZE (gfx950 counts half of a wide read)
+# (profiles/r1/cornell_1080p_1024spp_v2_hbm_traffic_pmc.txt): 2 x FETCH_SIZE (gfx950 counts half of a wide read)
 # + WRITE_SIZE, in KiB. It is the float4 accumulation buffer read and written once: 2 x 33.2 MB.
-MEASURED_TRAFFIC_BYTES = {("cornell", 1920, 1080, 1024): (2 * 16310.875 + 33412.5) * 1024}
+MEASURED_TRAFFIC_BYTES = {("cornell", 1920, 1080, 1024): (2 * 16322.0625 + 34425.0) * 1024}
 
 
 def cpu_baseline(scene, width, height, depth, target_seconds=12.0):
