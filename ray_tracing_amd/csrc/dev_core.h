@@ -256,49 +256,6 @@ MIRT_DEV void axis_indexes(uint32_t axis, uint32_t& xi, uint32_t& yi, uint32_t& 
     zi = axis == 0 ? 2u : (axis == 1 ? 1u : 0u);
 }
 
-// geo.rs:196-204 — zero-thickness plane, inclusive range and extent tests. Written in accepting
-// form so that a NaN t (direction parallel to the plane) is a miss. XI, YI, ZI = geo.rs:160-166.
-template <uint32_t XI, uint32_t YI, uint32_t ZI>
-MIRT_DEV bool rect_hit_axis(const DevPrim& p, const LRay& l, float t_min, float t_max, float& t_out) {
-    float k = p.a[0];
-    float t = div_nr(k - comp(l.r.o, ZI), comp(l.r.d, ZI), comp(l.rinv, ZI));
-    float x = comp(l.r.o, XI) + t * comp(l.r.d, XI);
-    float y = comp(l.r.o, YI) + t * comp(l.r.d, YI);
-    bool h = (t >= t_min) & (t <= t_max) & (x >= p.a[1]) & (x <= p.a[2]) & (y >= p.a[3]) & (y <= p.b[0]);
-    t_out = t;
-    return h;
-}
-
-// UNIFORM: the primitive record is the same for every lane (list scans), so the axis is chosen by a
-// scalar branch; otherwise (BVH leaves) by per-lane selects.
-template <bool UNIFORM>
-MIRT_DEV bool rect_hit(const DevPrim& p, const LRay& l, float t_min, float t_max, float& t_out) {
-    uint32_t axis = (p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT;
-    if (UNIFORM) {
-        if (axis == 0) return rect_hit_axis<0, 1, 2>(p, l, t_min, t_max, t_out);
-        if (axis == 1) return rect_hit_axis<0, 2, 1>(p, l, t_min, t_max, t_out);
-        return rect_hit_axis<1, 2, 0>(p, l, t_min, t_max, t_out);
-    }
-    uint32_t xi, yi, zi;
-    axis_indexes(axis, xi, yi, zi);
-    float k = p.a[0];
-    float t = div_nr(k - comp(l.r.o, zi), comp(l.r.d, zi), comp(l.rinv, zi));
-    float x = comp(l.r.o, xi) + t * comp(l.r.d, xi);
-    float y = comp(l.r.o, yi) + t * comp(l.r.d, yi);
-    bool h = (t >= t_min) & (t <= t_max) & (x >= p.a[1]) & (x <= p.a[2]) & (y >= p.a[3]) & (y <= p.b[0]);
-    t_out = t;
-    return h;
-}
-
-template <uint32_t F, bool UNIFORM>
-MIRT_DEV bool leaf_hit(const DevPrim& p, const LRay& l, float t_min, float t_max, float& t_out) {
-    uint32_t kind = p.meta & PM_KIND_MASK;
-    if ((F & F_SPHERE) && (!(F & F_RECT) || kind == PK_SPHERE))
-        return sphere_hit_c(sphere_center<F>(p, l.r.time), p.a[3], l.r, t_min, t_max, t_out);
-    if ((F & F_RECT) && kind == PK_RECT) return rect_hit<UNIFORM>(p, l, t_min, t_max, t_out);
-    return false;
-}
-
 // Where the medium free-path draws of one ray come from.
 struct DrawKey {
     uint32_t pixel, sample, bounce, seed;
