@@ -454,7 +454,8 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, Walk& w, uint32_t* stack
     const float tf0 = fminf(fminf(fmaxf(l0.x, h0.x), fmaxf(l0.y, h0.y)), fminf(fmaxf(z0.x, z0.y), w.closest));
     const float tn1 = fmaxf(fmaxf(fminf(l1.x, h1.x), fminf(l1.y, h1.y)), fmaxf(fminf(z1.x, z1.y), t_min));
     const float tf1 = fminf(fminf(fmaxf(l1.x, h1.x), fmaxf(l1.y, h1.y)), fminf(fmaxf(z1.x, z1.y), w.closest));
-    const bool hit0 = tn0 <= tf0 * 1.0000004f, hit1 = tn1 <= tf1 * 1.0000004f;
+    // (the missing second child of a single-leaf tree has no reference; its empty box would pass the test)
+    const bool hit0 = tn0 <= tf0 * 1.0000004f, hit1 = (tn1 <= tf1 * 1.0000004f) & (refs.y != kWalkIdle);
     if (hit0 && hit1) {
         const bool first0 = tn0 <= tn1;
         w.ref = first0 ? refs.x : refs.y;

@@ -419,6 +419,51 @@ def test_ragged_frame_sizes(rt, oracle, earth, w, h):
     assert frame.shape == (h, w, 4) and (frame[..., 3] == 255).all()
 
 
+def _sphere_scene(rt, centres, radius, entry_kind):
+    """A hand-made descriptor: spheres with one Lambertian material in a single world entry of the given kind."""
+    C = rt.C
+    n = len(centres)
+    prims = (rt.mirt_prim * n)()
+    for p, c in zip(prims, centres):
+        p.kind, p.material, p.radius = 0, 0, radius
+        p.center0[0], p.center0[1], p.center0[2] = c
+    mats = (rt.mirt_material * 1)()
+    texs = (rt.mirt_texture * 1)()
+    texs[0].color[0] = texs[0].color[1] = texs[0].color[2] = 0.5
+    world = (rt.mirt_entry * 1)()
+    world[0].kind, world[0].first_prim, world[0].prim_count, world[0].prims_per_object = entry_kind, 0, n, 1
+    inst = (rt.mirt_instance * 1)()
+    d = rt.mirt_scene_desc()
+    d.prims, d.n_prims = prims, n
+    d.world, d.n_world = world, 1
+    d.materials, d.n_materials = mats, 1
+    d.textures, d.n_textures = texs, 1
+    d.instances, d.n_instances = inst, 1
+    d.background[0] = d.background[1] = d.background[2] = 1.0
+    d._keep = (prims, mats, texs, world, inst)
+    return d
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 40])
+def test_small_hierarchies_equal_lists(rt, n):
+    """A hierarchy entry returns what the same primitives return as a plain list, down to trees of a single
+    leaf (one or two members) and up to a list long enough to be given a hierarchy automatically."""
+    rng = np.random.default_rng(n)
+    centres = rng.uniform(-3, 3, (n, 3)).astype(np.float32).tolist()
+    o = rng.uniform(-6, 6, (4000, 3)).astype(np.float32)
+    d = -o + rng.normal(scale=1.5, size=o.shape).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([o, d, np.zeros((len(o), 1), np.float32)], axis=1).astype(np.float32)
+    res = []
+    for kind in (0, 1):   # MIRT_ENTRY_LIST, MIRT_ENTRY_BVH
+        ctx = rt.Context(0)
+        ctx.scene_upload(_sphere_scene(rt, centres, 0.8, kind))
+        res.append(ctx.first_hit(rays))
+    (li, lt), (bi, bt) = res
+    assert (li >= 0).mean() > 0.02
+    assert (li == bi).all() and (lt == bt).all()
+
+
 def test_empty_world_and_zero_samples(rt):
     """An empty world (scene.rs:290 with no objects) returns the background for every ray; zero samples or
     zero depth leave the sums untouched (renderer.rs:100, 198-200)."""
