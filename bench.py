@@ -137,7 +137,11 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} {W}x{H}, {spp} spp per GPU, max depth {args.depth}, light+cosine mixture pdf",
                        "samples_per_step": samples_per_step, "parallelism": f"spp-range x{world}" + (" + RCCL reduce" if world > 1 else "")},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            # compute-bound, not HBM-bound: of the two roofline categories this is the arithmetic one. A path tracer
+            # has no matrix products, so the arithmetic runs on the vector ALUs; for f32 the vector peak and the
+            # dense MFMA peak of the MI355X are the same 157.3 TFLOP/s.
+            "roofline": {"bound": "mfma", "bound_note": "f32 vector-ALU issue bound (no matrix ops in this path); f32 VALU peak = f32 MFMA peak",
+                         "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "frac_of_unpacked_fma_rate": achieved / UNPACKED_FP32_TFLOPS,
                          "traffic": MEASURED_TRAFFIC_BYTES.get((args.scene, W, H, spp)), "traffic_unit": "bytes per launch (PMC, separate run)",
