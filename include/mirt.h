@@ -135,7 +135,12 @@ typedef struct mirt_camera {
 
 typedef struct mirt_ray { float origin[3], direction[3], time; } mirt_ray;
 
-enum { MIRT_KERNEL_AUTO = 0, MIRT_KERNEL_FUSED = 1, MIRT_KERNEL_WAVEFRONT = 2 };
+/* Which form of the sample loop renders: FUSED = one launch, one pixel per lane for the whole call; QUEUE = one
+ * persistent launch whose lanes draw pixels from a shared counter (lanes never wait for a tile's or the frame's
+ * most expensive pixel); WAVEFRONT = generate / extend / shade launches per ray segment with queues in memory
+ * (kept as the comparison baseline). AUTO takes QUEUE for scenes with a hierarchy and FUSED otherwise. All
+ * forms render the same samples. */
+enum { MIRT_KERNEL_AUTO = 0, MIRT_KERNEL_FUSED = 1, MIRT_KERNEL_WAVEFRONT = 2, MIRT_KERNEL_QUEUE = 3 };
 
 typedef struct mirt_render_params {
     uint32_t width, height;
@@ -152,7 +157,7 @@ typedef struct mirt_stats {
     uint64_t segments;     /* ray segments traced (ray_color levels that reached world.hit) */
     double kernel_ms;      /* GPU time of the last mirt_render, HIP events on the render stream */
     uint32_t kernel_launches; /* launches in the last mirt_render */
-    uint32_t kernel_used;  /* MIRT_KERNEL_FUSED or MIRT_KERNEL_WAVEFRONT */
+    uint32_t kernel_used;  /* MIRT_KERNEL_FUSED, MIRT_KERNEL_QUEUE or MIRT_KERNEL_WAVEFRONT */
     uint64_t lane_slots;   /* fused kernel: 64 x loop iterations summed over waves; segments / lane_slots =
                               share of lane-iterations that traced a segment (the rest idled in a wave whose
                               other lanes had longer paths) */

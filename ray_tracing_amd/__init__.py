@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("MIRT_LIB", os.path.join(_HERE, "libmirt.so"))  # MIRT
 ASSETS = os.path.join(_HERE, "assets")
 
 MIRT_OK = 0
-KERNEL_AUTO, KERNEL_FUSED, KERNEL_WAVEFRONT = 0, 1, 2
+KERNEL_AUTO, KERNEL_FUSED, KERNEL_WAVEFRONT, KERNEL_QUEUE = 0, 1, 2, 3
 
 # every symbol include/mirt.h and include/mirt_host.h declare
 EXPORTS = [

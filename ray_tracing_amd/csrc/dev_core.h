@@ -44,6 +44,25 @@ MIRT_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x
 MIRT_DEV float comp(V3 v, uint32_t i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 // per-component select (a struct-valued ?: makes hipcc index a two-element array in scratch memory)
 MIRT_DEV V3 select(bool c, V3 a, V3 b) { return V3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
+// A record of a scene table read through the constant address space. The scene arrays are never written
+// while a kernel runs, but the compiler cannot know that once the kernel also stores to global memory
+// inside its loop (the persistent render kernel writes finished pixels as it goes): reads it cannot prove
+// unclobbered become per-lane vector loads even when their address is wave-uniform. Constant-address-space
+// reads with a uniform address stay scalar loads (s_load_dwordx*), the data in SGPRs.
+template <class T>
+MIRT_DEV T load_const(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    constexpr int kWords = (int)(sizeof(T) / 4);
+    const __attribute__((address_space(4))) uint32_t* q = (const __attribute__((address_space(4))) uint32_t*)p;
+    union {
+        T value;
+        uint32_t words[kWords];
+    } u;
+#pragma unroll
+    for (int i = 0; i < kWords; ++i) u.words[i] = q[i];
+    return u.value;
+}
+
 // Two floats in a register pair: + - * and fma on them are single packed instructions (v_pk_add_f32,
 // v_pk_mul_f32, v_pk_fma_f32), each half rounded exactly as the scalar operation would be.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -331,13 +350,13 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
     LRay lr = make_lray(r);
     const DevScanRec* p = s.scan + first;
     for (uint32_t j = 0; j < count; ++j) {
-        const DevScanRec rec = p[j];
+        const DevScanRec rec = load_const(p + j);
         const uint32_t code = rec.code_inst & 0xffu;
         if (F & F_INSTANCE) {
             const uint32_t inst = rec.code_inst >> 8;
             if (inst != cur_inst) {
                 cur_inst = inst;
-                lr = make_lray(inst ? to_local(s.instances[inst], r) : r);
+                lr = make_lray(inst ? to_local(load_const(s.instances + inst), r) : r);
             }
         }
         float t = 0.f;
@@ -350,10 +369,10 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
         else if ((F & F_RECT) && code == SC_RECT_YZ) h = rect_rec_hit<1, 2, 0>(rec.f, lr, t_min, closest, t);
         else if ((F & F_SPHERE) && code == SC_SPHERE) h = sphere_hit_c(v3(rec.f), rec.f[3], lr.r, t_min, closest, t);
         else if ((F & F_MOVING) && code == SC_SPHERE_MOVING) {
-            const DevPrim& q = s.prims[rec.prim];
+            const DevPrim q = load_const(s.prims + rec.prim);
             h = sphere_hit_c(sphere_center<F>(q, lr.r.time), q.a[3], lr.r, t_min, closest, t);
         } else if (ALLOW_MEDIUM && (F & F_MEDIUM) && code == SC_MEDIUM) {
-            h = medium_hit<F>(s, s.prims[rec.prim], r, t_min, closest, key, t);
+            h = medium_hit<F>(s, load_const(s.prims + rec.prim), r, t_min, closest, key, t);
         }
         closest = h ? t : closest;
         best = h ? (int)rec.prim : best;
@@ -538,7 +557,7 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
 template <uint32_t F>
 MIRT_DEV void world_lists(const DevScene& s, const Ray& r, const DrawKey& key, float& closest, int& best) {
     for (uint32_t e = 0; e < s.n_entries; ++e) {
-        const DevEntry& en = s.entries[e];
+        const DevEntry en = load_const(s.entries + e);
         if (!(F & F_BVH) || en.kind != EK_BVH) list_scan<F, true>(s, en.scan_first, en.scan_count, r, 0.001f, key, closest, best);
     }
 }
@@ -751,7 +770,7 @@ template <uint32_t F>
 MIRT_DEV float lights_pdf(const DevScene& s, V3 origin, V3 v) {
     V3 vinv = v3(fast_rcp(v.x), fast_rcp(v.y), fast_rcp(v.z));
     float sum = 0.f;
-    for (uint32_t i = 0; i < s.n_lights; ++i) sum += light_pdf_one<F>(s.light_prims[i], origin, v, vinv);
+    for (uint32_t i = 0; i < s.n_lights; ++i) sum += light_pdf_one<F>(load_const(s.light_prims + i), origin, v, vinv);
     return sum * fast_rcp((float)s.n_lights);
 }
 

@@ -13,7 +13,12 @@ struct RenderArgs {
     uint32_t max_depth, seed, jitter;
     float4* accum;                      // width*height, pixel y*width + x, y = 0 at the bottom
     unsigned long long* segment_counter;
+    uint32_t* work_counter;             // pixel queue of the persistent kernel: zero before every launch
+    uint32_t loop;                      // LOOP_*
 };
+enum : uint32_t { LOOP_AUTO = 0, LOOP_FUSED = 1, LOOP_QUEUE = 2 };
+// Whether launch_render_fused() renders these arguments with the persistent pixel-queue kernel.
+bool render_uses_queue(const RenderArgs& a);
 
 struct RayBatchArgs {
     DevScene scene;

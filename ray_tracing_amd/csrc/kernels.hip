@@ -9,6 +9,8 @@
 //   first_hit_kernel     world.hit(ray, 0.001, inf) for explicit rays (deterministic check).
 //   ray_color_kernel     one un-sanitised radiance sample per explicit ray.
 //   resolve_kernel       mean, clamp, sqrt, *256 -> RGBA8 with the row flip (renderer.rs:97,109-116).
+#include <algorithm>
+#include <cstdlib>
 #include "kernels.h"
 #include "dev_core.h"
 
@@ -187,6 +189,215 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(Rend
     finish_pixel(a, valid, pixel, acc, segments, segments);
 }
 
+// The sample loop as a persistent kernel. The grid is only as large as the device holds at once; every
+// wave draws pixels from one global counter, 64 indices at a time (index -> 8x8 tile, pixel within the
+// tile), and a lane that has finished all samples of its pixel adds the sums to the accumulation buffer
+// and takes the next index in the same iteration. Nothing waits for the most expensive pixel of a tile
+// or the most expensive tile of a launch: lanes idle only while the last pixels of the whole launch
+// finish. A pixel is rendered by exactly one lane, sample after sample, so the sums are the ones of the
+// kernel above, bit for bit.
+struct PixelQueue {
+    uint32_t pos, end;  // the wave's current run of pixel indices (wave-uniform)
+    bool drained;       // the global counter has passed the last index
+};
+
+// Hands a pixel index to every lane with `need` (0xffffffff once the launch has no pixels left).
+__device__ __forceinline__ uint32_t take_pixels(bool need, PixelQueue& q, uint32_t* counter, uint32_t total) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t idx = 0xffffffffu;
+    for (;;) {
+        const unsigned long long m = __ballot(need && idx == 0xffffffffu);
+        if (m == 0) break;
+        if (q.pos == q.end) {
+            if (q.drained) break;
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(counter, 64u);
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c >= total) {
+                q.drained = true;
+                break;
+            }
+            q.pos = c;
+            q.end = min(c + 64u, total);
+        }
+        const uint32_t avail = q.end - q.pos;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (need && idx == 0xffffffffu && rank < avail) idx = q.pos + rank;
+        q.pos += min((uint32_t)__popcll(m), avail);
+    }
+    return idx;
+}
+
+template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
+__global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(RenderArgs a) {
+    // the LDS-table variants are only launched for scenes without a hierarchy: no traversal code, no stack
+    constexpr uint32_t FT = LDS_TABLES ? (F & ~(uint32_t)F_BVH) : F;
+    __shared__ uint32_t bvh_stack[(FT & F_BVH) ? kBvhStackDepth * kBlock : 1];
+    __shared__ DevPrim s_prims[LDS_TABLES ? kLdsPrims : 1];
+    __shared__ DevShade s_shade[LDS_TABLES ? kLdsPrims : 1];
+    __shared__ DevInstance s_inst[LDS_TABLES ? kLdsInstances : 1];
+    __shared__ DevPrim s_lights[LDS_TABLES ? kLdsLights : 1];
+    uint32_t* stack = bvh_stack + threadIdx.x;
+
+    Tables tb;
+    if (LDS_TABLES) {
+        copy_to_lds(s_prims, a.scene.prims, a.scene.n_prims);
+        copy_to_lds(s_shade, a.scene.shade, a.scene.n_prims);
+        copy_to_lds(s_inst, a.scene.instances, a.scene.n_instances);
+        copy_to_lds(s_lights, a.scene.light_prims, a.scene.n_lights);
+        __syncthreads();
+        tb = Tables{s_prims, s_shade, s_inst, s_lights};
+    } else {
+        tb = Tables{a.scene.prims, a.scene.shade, a.scene.instances, a.scene.light_prims};
+    }
+
+    const uint32_t tiles_x = (a.width + 7u) / 8u, tiles_y = (a.height + 7u) / 8u;
+    const uint32_t total = tiles_x * tiles_y * 64u;
+    const bool jitter = a.jitter != 0;
+    const uint32_t sample_end = a.spp_begin + a.spp_count;
+    PixelQueue q{0u, 0u, false};
+
+    // the lane's pixel and its path
+    uint32_t pixel = 0, x = 0, y = 0, sample = a.spp_begin;
+    V3 acc = v3(0.f, 0.f, 0.f);
+    bool alive = false;
+    uint32_t depth_left = a.max_depth, bounce = 0;
+    Ray ray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f), 0.f};
+    V3 thr = v3(1.f, 1.f, 1.f);
+    uint32_t segments = 0, rounds = 0;
+
+    // Gives the lanes with `need` their next pixel: position, first sample, empty sums. Indices of the edge
+    // tiles that lie outside the frame are skipped. A lane that gets none is done (alive = false).
+    // (the closures below capture copies of the few launch arguments they need: a reference to the
+    // argument block would move it to memory and turn every scene read into a per-lane load)
+    uint32_t* const work_counter = a.work_counter;
+    float4* const accum = a.accum;
+    const uint32_t width = a.width, height = a.height, spp_begin = a.spp_begin;
+    const float spp_count = (float)a.spp_count;
+    auto next_pixel = [&q, &alive, &x, &y, &pixel, &sample, &acc, work_counter, total, tiles_x, width, height, spp_begin](bool need) {
+        for (;;) {
+            if (__ballot(need) == 0) break;
+            const uint32_t idx = take_pixels(need, q, work_counter, total);
+            if (need) {
+                alive = idx != 0xffffffffu;
+                if (alive) {
+                    const uint32_t tile = idx >> 6, in = idx & 63u;
+                    x = (tile % tiles_x) * 8u + (in & 7u);
+                    y = (tile / tiles_x) * 8u + (in >> 3);
+                    pixel = y * width + x;
+                    sample = spp_begin;
+                    acc = v3(0.f, 0.f, 0.f);
+                }
+                need = alive && !(x < width && y < height);  // outside the frame: take another
+            }
+        }
+    };
+    // The lane's pixel has all its samples: renderer.rs:107-110 for the whole pixel.
+    auto flush_pixel = [&pixel, &acc, accum, spp_count]() {
+        float4 v = accum[pixel];
+        v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += spp_count;
+        accum[pixel] = v;
+    };
+
+    next_pixel(true);
+    if (alive) {
+        Rng g;
+        g.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
+        ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, g);
+    }
+    while (__ballot(alive) != 0) {
+        ++rounds;
+        // ---- trace: scene.world.hit (renderer.rs:201)
+        float t = MIRT_INF;
+        int prim = -1;
+        if (alive) {
+            DrawKey key{pixel, sample, bounce, a.seed};
+            world_hit<FT>(a.scene, ray, key, stack, kBlock, t, prim);
+            ++segments;
+        }
+        // ---- classify; paths that end here without drawing (miss, emitter) are closed first
+        HitInfo h;
+        DevShade m;
+        bool ended = false;
+        if (alive) {
+            V3 e = v3(0.f, 0.f, 0.f);
+            if (prim < 0) {
+                e = cmul(thr, v3(a.scene.background));  // renderer.rs:233-235
+                ended = true;
+            } else {
+                m = tb.shade[prim];
+                h = finalize_hit<F>(tb, ray, t, prim);
+                if ((F & F_MAT_LIGHT) && m.mat_kind == MK_DIFFUSE_LIGHT) {
+                    e = cmul(thr, emitted_radiance<F>(a.scene, m, h));
+                    ended = true;
+                }
+            }
+            if (ended) {
+                acc = acc + v3(sanitize(e.x), sanitize(e.y), sanitize(e.z));  // renderer.rs:107-109
+                ++sample;
+            }
+        }
+        // ---- pixels that are complete go out, their lanes take the next pixel of the launch
+        {
+            const bool done = alive && ended && sample == sample_end;
+            if (__ballot(done) != 0) {
+                if (done) flush_pixel();
+                next_pixel(done);
+            }
+        }
+        // ---- one Philox block per lane and iteration serves whichever branch the lane takes next:
+        //      the camera stream of its next sample, or the scatter stream of this bounce
+        const uint32_t r_bounce = ended ? 0u : bounce;
+        const uint32_t r_stream = ended ? (uint32_t)STREAM_CAMERA : (uint32_t)STREAM_SCATTER;
+        uint32_t w0, w1, w2, w3;
+        philox4x32_10(pixel, sample, 0u, r_bounce, r_stream, a.seed, w0, w1, w2, w3);
+        Rng g;
+        g.init_with_block0(pixel, sample, r_bounce, r_stream, a.seed, w0, w1, w2, w3);
+
+        bool over = false;  // path closed after its scatter draws: needs a camera ray from a fresh stream
+        if (alive && !ended) {
+            const bool cont = scatter<F>(a.scene, tb, m, h, g, ray, thr);
+            --depth_left;
+            ++bounce;
+            if (!cont || depth_left == 0) {  // absorbed, or renderer.rs:198-200: the next level returns 0
+                ++sample;
+                over = true;
+            }
+        } else if (alive) {
+            ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, g);
+            thr = v3(1.f, 1.f, 1.f);
+            depth_left = a.max_depth;
+            bounce = 0;
+        }
+        if (__ballot(over) != 0) {
+            const bool done = over && sample == sample_end;
+            if (__ballot(done) != 0) {
+                if (done) flush_pixel();
+                next_pixel(done);
+            }
+            if (over && alive) {
+                Rng gc;
+                gc.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
+                ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, gc);
+                thr = v3(1.f, 1.f, 1.f);
+                depth_left = a.max_depth;
+                bounce = 0;
+            }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) segments += __shfl_down(segments, off);
+    if ((threadIdx.x & 63u) == 0 && a.segment_counter) {
+        atomicAdd(a.segment_counter, (unsigned long long)segments);
+        atomicAdd(a.segment_counter + 1, 64ull * rounds);
+    }
+}
+
+// max_depth == 0: ray_color returns black at once (renderer.rs:198-200); the samples still count.
+__global__ __launch_bounds__(kBlock) void count_samples_kernel(float4* accum, uint32_t n, float spp) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) accum[i].w += spp;
+}
+
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
     __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
@@ -290,6 +501,22 @@ static hipError_t dispatch(uint32_t features, const Args& a, hipStream_t stream)
     return Launcher<kVariantAll>::run(a, stream);
 }
 
+// A persistent launch: as many workgroups as the device keeps resident at once (never more than the
+// frame has work for); the waves share out the pixels through a.work_counter, which the caller zeroed.
+template <class Kernel>
+static hipError_t launch_persistent(Kernel kernel, const RenderArgs& a, hipStream_t stream) {
+    int device = 0, cus = 0, per_cu = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0)) != hipSuccess) return e;
+    const uint32_t pixels = ((a.width + 7u) / 8u) * ((a.height + 7u) / 8u) * 64u;
+    const uint32_t want = (pixels + kBlock - 1) / kBlock;
+    const uint32_t resident = (uint32_t)std::max(cus * per_cu, 1);
+    hipLaunchKernelGGL(kernel, dim3(std::min(want, resident)), dim3(kBlock), 0, stream, a);
+    return hipGetLastError();
+}
+
 template <uint32_t F>
 struct RenderLauncher {
     static hipError_t run(const RenderArgs& a, hipStream_t stream) {
@@ -298,6 +525,21 @@ struct RenderLauncher {
         const bool lds = s.n_prims <= kLdsPrims && s.n_instances <= kLdsInstances && s.n_lights <= kLdsLights;
         const bool pinhole = a.cam.lens_radius == 0.f && !(s.features & F_MOVING);
         dim3 grid(tiles), block(kBlock);
+        // Which loop: scenes with a hierarchy have paths of very unequal cost and gain 8-16 % from the pixel
+        // queue; the list scenes are VALU-issue bound, their lanes are 92 % busy already, and the queue's
+        // bookkeeping costs them more than the idle lanes it recovers (Cornell 11.1 against 13.2 Gsamples/s).
+        if (render_uses_queue(a)) {
+            if (a.max_depth == 0) {
+                const uint32_t n = a.width * a.height;
+                hipLaunchKernelGGL(count_samples_kernel, dim3((n + kBlock - 1) / kBlock), block, 0, stream, a.accum, n, (float)a.spp_count);
+                return hipGetLastError();
+            }
+            const bool lq = lds && !(s.features & F_BVH);  // the LDS-table variants carry no traversal stack
+            if (lq && pinhole) return launch_persistent(render_queue_kernel<F, true, true>, a, stream);
+            if (lq) return launch_persistent(render_queue_kernel<F, true, false>, a, stream);
+            if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, a, stream);
+            return launch_persistent(render_queue_kernel<F, false, false>, a, stream);
+        }
         if (lds && pinhole) hipLaunchKernelGGL((render_fused_kernel<F, true, true>), grid, block, 0, stream, a);
         else if (lds) hipLaunchKernelGGL((render_fused_kernel<F, true, false>), grid, block, 0, stream, a);
         else if (pinhole) hipLaunchKernelGGL((render_fused_kernel<F, false, true>), grid, block, 0, stream, a);
@@ -320,6 +562,13 @@ struct RayColorLauncher {
     }
 };
 
+bool render_uses_queue(const RenderArgs& a) {
+    // the environment variable overrides an AUTO choice for A/B runs of whole programs
+    static const int env = [] { const char* e = std::getenv("MIRT_QUEUE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    if (!a.work_counter || a.loop == LOOP_FUSED) return false;
+    if (a.loop == LOOP_QUEUE) return true;
+    return env >= 0 ? env == 1 : (a.scene.features & F_BVH) != 0;
+}
 hipError_t launch_render_fused(const RenderArgs& a, hipStream_t stream) {
     if (a.width == 0 || a.height == 0 || a.spp_count == 0) return hipSuccess;
     return dispatch<RenderLauncher>(a.scene.features, a, stream);

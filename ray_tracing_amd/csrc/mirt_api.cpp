@@ -167,8 +167,9 @@ int mirt_create(int device, mirt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), kCounters * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(c->seg_counter, 0, kCounters * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    // kCounters statistics words, then the pixel queue of the persistent render kernel
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), (kCounters + 1) * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->seg_counter, 0, (kCounters + 1) * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
     *out = c;
     return MIRT_OK;
 }
@@ -675,7 +676,7 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     if (!c->accum || p->width != c->width || p->height != c->height)
         return fail(c, MIRT_ERR_STATE, "mirt_render: width/height differ from mirt_frame_begin");
     if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, "mirt_render: sample range overflows 32 bits");
-    if (p->kernel > MIRT_KERNEL_WAVEFRONT) return fail(c, MIRT_ERR_INVALID, "mirt_render: unknown kernel selector");
+    if (p->kernel > MIRT_KERNEL_QUEUE) return fail(c, MIRT_ERR_INVALID, "mirt_render: unknown kernel selector");
     HIP_TRY(c, hipSetDevice(c->device));
     // depth 0 traces nothing (renderer.rs:198-200): the fused kernel just counts the samples
     if (p->kernel == MIRT_KERNEL_WAVEFRONT && p->max_depth > 0) return render_wavefront(c, p);
@@ -686,6 +687,8 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     a.max_depth = p->max_depth; a.seed = p->seed; a.jitter = p->jitter;
     a.accum = c->accum;
     a.segment_counter = c->seg_counter;
+    a.work_counter = reinterpret_cast<uint32_t*>(c->seg_counter + kCounters);
+    a.loop = p->kernel == MIRT_KERNEL_FUSED ? LOOP_FUSED : (p->kernel == MIRT_KERNEL_QUEUE ? LOOP_QUEUE : LOOP_AUTO);
     // Long renders are cut into launches of at most kChunk samples per pixel: lanes of a wave
     // then finish within a few percent of each other and no launch runs for seconds.
     uint32_t kChunk = 1024;  // measured on Cornell 1080p: 64 -> 9.5, 256 -> 10.6, 1024 -> 11.2 Gsamples/s (fewer launch tails)
@@ -695,13 +698,14 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     for (uint32_t done = 0; done < p->spp_count; done += kChunk) {
         a.spp_begin = p->spp_begin + done;
         a.spp_count = std::min(kChunk, p->spp_count - done);
+        HIP_TRY(c, hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), c->stream));
         HIP_TRY(c, launch_render_fused(a, c->stream));
         ++launches;
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->stats.samples += (uint64_t)p->width * p->height * p->spp_count;
     c->stats.kernel_launches = launches;
-    c->stats.kernel_used = MIRT_KERNEL_FUSED;
+    c->stats.kernel_used = render_uses_queue(a) ? MIRT_KERNEL_QUEUE : MIRT_KERNEL_FUSED;
     return MIRT_OK;
 }
 

@@ -409,7 +409,7 @@ def test_ragged_frame_sizes(rt, oracle, earth, w, h):
     rendered exactly once per sample, by both kernel sets, and matches the oracle."""
     orc, ctx, _ = make(rt, oracle, earth, "cornell", w, h)
     want, _ = orc.render_sums(8, 50, seed=2)
-    for kernel in (rt.KERNEL_FUSED, rt.KERNEL_WAVEFRONT):
+    for kernel in (rt.KERNEL_FUSED, rt.KERNEL_QUEUE, rt.KERNEL_WAVEFRONT):
         ctx.frame_begin(w, h)
         ctx.render(8, 50, seed=2, kernel=kernel)
         acc = ctx.read_accum()
@@ -417,6 +417,29 @@ def test_ragged_frame_sizes(rt, oracle, earth, w, h):
         assert np.isclose(acc[..., :3], want, rtol=5e-3, atol=2e-3).all(axis=2).mean() > 0.95
     frame = ctx.resolve_rgba8()
     assert frame.shape == (h, w, 4) and (frame[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("name,spp,size", [("cornell", 24, (64, 36)), ("smoke", 8, (64, 36)), ("random", 8, (64, 36)),
+                                           ("final", 4, (64, 36)), ("2psp", 8, (37, 19)), ("random", 3, (130, 70))])
+def test_pixel_queue_kernel_equals_fused_kernel(rt, oracle, earth, name, spp, size):
+    """The persistent kernel (lanes draw pixels from a shared counter) renders every pixel in one lane, sample
+    after sample, exactly as the one-pixel-per-lane kernel does: the sums are equal bit for bit, whichever lane
+    took which pixel, and so are the segment counts. AUTO picks it for scenes with a hierarchy."""
+    w, h = size
+    orc, ctx, _ = make(rt, oracle, earth, name, w, h)
+    out = {}
+    for kernel in (rt.KERNEL_FUSED, rt.KERNEL_QUEUE, rt.KERNEL_AUTO):
+        ctx.frame_begin(w, h)
+        ctx.render(spp, 50, seed=8, kernel=kernel)
+        ctx.render(2, 50, spp_begin=spp, seed=8, kernel=kernel)     # a second sample range on top
+        st = ctx.stats()
+        out[kernel] = (ctx.read_accum(), st["segments"], st["kernel_used"])
+    assert out[rt.KERNEL_FUSED][2] == rt.KERNEL_FUSED and out[rt.KERNEL_QUEUE][2] == rt.KERNEL_QUEUE
+    assert out[rt.KERNEL_AUTO][2] == (rt.KERNEL_QUEUE if name in ("random", "final") else rt.KERNEL_FUSED)
+    assert (out[rt.KERNEL_QUEUE][0] == out[rt.KERNEL_FUSED][0]).all()
+    assert (out[rt.KERNEL_AUTO][0] == out[rt.KERNEL_FUSED][0]).all()
+    assert out[rt.KERNEL_QUEUE][1] == out[rt.KERNEL_FUSED][1]
+    assert (out[rt.KERNEL_FUSED][0][..., 3] == spp + 2).all()
 
 
 def _sphere_scene(rt, centres, radius, entry_kind):
