@@ -25,11 +25,11 @@ FLOP_PER_SEGMENT = 400.0       # algorithmic FLOP of one Cornell path segment (1
 # list scenes emits no packed arithmetic, so the fraction of that rate is reported beside `frac`.
 PEAK_FP32_VALU_TFLOPS = 157.3
 UNPACKED_FP32_TFLOPS = 78.6
-# HBM bytes of one render launch of the default workload, from rocprofv3 PMC passes
-# (profiles/r1/cornell_1080p_1024spp_v2_hbm_traffic_pmc.txt): 2 x FETCH_SIZE (gfx950 counts half of a wide read)
-# + WRITE_SIZE, in KiB. It is the float4 accumulation buffer read and written once: 2 x 33.2 MB.
-MEASURED_TRAFFIC_BYTES = {("cornell", 1920, 1080, 1024): (2 * 16322.0625 + 34425.0) * 1024}
-
+# HBM bytes of one launch of the render kernel on the default workload, from rocprofv3 PMC passes
+# (profiles/r1/cornell_1080p_1024spp_v3_hbm_traffic_pmc.txt): 2 x FETCH_SIZE (gfx950 counts half of a wide read)
+# + WRITE_SIZE, in KiB. The persistent kernel writes one float4 per pixel and sample chunk (16 chunks x 33.2 MB)
+# and reads next to nothing; the pass that adds the chunks (reduce_chunks_kernel, 0.1 ms) reads them back once.
+MEASURED_TRAFFIC_BYTES = {("cornell", 1920, 1080, 1024): (2 * 9197.375 + 566903.3125) * 1024}
 
 def cpu_baseline(scene, width, height, depth, target_seconds=12.0):
     """The oracle (CPU restatement of the reference renderer) on this host's cores, on a bounded sample of
@@ -145,7 +145,7 @@ def main():
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "frac_of_unpacked_fma_rate": achieved / UNPACKED_FP32_TFLOPS,
                          "traffic": MEASURED_TRAFFIC_BYTES.get((args.scene, W, H, spp)), "traffic_unit": "bytes per launch (PMC, separate run)",
-                         "kernel": "render_fused_kernel", "avg_launch_ms": kernel_ms / max(launches, 1),
+                         "kernel": "render_queue_kernel", "avg_launch_ms": kernel_ms / max(launches, 1),
                          "segments_per_sample": segments / (W * H * spp * args.steps),
                          "gsegments_per_s": segments / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
                          "flop_per_segment": FLOP_PER_SEGMENT},

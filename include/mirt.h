@@ -136,10 +136,11 @@ typedef struct mirt_camera {
 typedef struct mirt_ray { float origin[3], direction[3], time; } mirt_ray;
 
 /* Which form of the sample loop renders: FUSED = one launch, one pixel per lane for the whole call; QUEUE = one
- * persistent launch whose lanes draw pixels from a shared counter (lanes never wait for a tile's or the frame's
- * most expensive pixel); WAVEFRONT = generate / extend / shade launches per ray segment with queues in memory
- * (kept as the comparison baseline). AUTO takes QUEUE for scenes with a hierarchy and FUSED otherwise. All
- * forms render the same samples. */
+ * persistent launch whose lanes draw (pixel, chunk of samples) items from a shared counter, so that no lane waits
+ * for a tile's or the frame's most expensive pixel, followed by a pass that adds the chunk sums of every pixel in
+ * chunk order; WAVEFRONT = generate / extend / shade launches per ray segment with queues in memory (kept as the
+ * comparison baseline). AUTO takes QUEUE. All forms render the same samples; QUEUE and FUSED differ only in the
+ * grouping of the float additions of a pixel's samples (none when spp_count is 1). */
 enum { MIRT_KERNEL_AUTO = 0, MIRT_KERNEL_FUSED = 1, MIRT_KERNEL_WAVEFRONT = 2, MIRT_KERNEL_QUEUE = 3 };
 
 typedef struct mirt_render_params {

@@ -553,6 +553,46 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
     }
 }
 
+// A bounded piece of the same walk: at most `budget` node and leaf steps for this lane, continuing where
+// the lane's last call stopped (w.next hierarchies started, w.ref / stack as left). Returns true when
+// the walk is complete. A render loop that calls this once per iteration lets the lanes whose walk is
+// over shade and start their next segment while a lane with a long walk (a ray through a dense cluster)
+// keeps its place and goes on in the next iteration, instead of the whole wave waiting for it.
+#ifdef MIRT_WALK_STATS
+static __device__ unsigned long long g_walk_hist[16];
+static __device__ unsigned long long g_phase[4];
+static __device__ unsigned long long g_life[4];
+static __device__ uint32_t g_walk_steps_dummy;
+#define g_walk_steps walk_steps_out
+#endif
+template <uint32_t F>
+MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t* stack,
+                        uint32_t stride
+#ifdef MIRT_WALK_STATS
+                        , uint32_t& walk_steps_out
+#endif
+                        ) {
+    uint32_t steps = 0;
+    for (;;) {
+        if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w);
+        while (w.ref != kWalkIdle && steps < budget) {
+            while (ref_is_node(w.ref) && steps < budget) {
+                walk_node(s, t_min, w, stack, stride);
+                ++steps;
+            }
+            if (ref_is_leaf(w.ref)) {
+                walk_leaf<F>(s, t_min, w, stack, stride);
+                ++steps;
+            }
+        }
+        if (w.ref != kWalkIdle || w.next >= n) break;  // out of budget, or every hierarchy walked
+    }
+#ifdef MIRT_WALK_STATS
+    g_walk_steps = steps;
+#endif
+    return w.ref == kWalkIdle;
+}
+
 // The list entries of the world, in world order (HittableList::hit, ray.rs:123-133).
 template <uint32_t F>
 MIRT_DEV void world_lists(const DevScene& s, const Ray& r, const DrawKey& key, float& closest, int& best) {

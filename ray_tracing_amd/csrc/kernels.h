@@ -15,6 +15,12 @@ struct RenderArgs {
     unsigned long long* segment_counter;
     uint32_t* work_counter;             // pixel queue of the persistent kernel: zero before every launch
     uint32_t loop;                      // LOOP_*
+    uint32_t walk_budget;               // hierarchy steps per lane and iteration of the persistent kernel
+    // The persistent kernel's work items are (pixel, chunk of chunk_spp samples): n_chunks per pixel. With
+    // more than one chunk the item sums go to partial[chunk * width * height + pixel] and are added to
+    // accum in chunk order by a second kernel.
+    uint32_t n_chunks, chunk_spp;
+    float4* partial;
 };
 enum : uint32_t { LOOP_AUTO = 0, LOOP_FUSED = 1, LOOP_QUEUE = 2 };
 // Whether launch_render_fused() renders these arguments with the persistent pixel-queue kernel.

@@ -252,19 +252,29 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     }
 
     const uint32_t tiles_x = (a.width + 7u) / 8u, tiles_y = (a.height + 7u) / 8u;
-    const uint32_t total = tiles_x * tiles_y * 64u;
+    const uint32_t per_chunk = tiles_x * tiles_y * 64u;  // work items of one sample chunk: every pixel slot of every tile
+    const uint32_t total = per_chunk * a.n_chunks;
     const bool jitter = a.jitter != 0;
-    const uint32_t sample_end = a.spp_begin + a.spp_count;
     PixelQueue q{0u, 0u, false};
 
-    // the lane's pixel and its path
-    uint32_t pixel = 0, x = 0, y = 0, sample = a.spp_begin;
+    // the lane's work item (a pixel and a run of its samples) and its path
+    uint32_t pixel = 0, x = 0, y = 0, sample = a.spp_begin, sample_end = a.spp_begin, slot = 0;
     V3 acc = v3(0.f, 0.f, 0.f);
     bool alive = false;
     uint32_t depth_left = a.max_depth, bounce = 0;
     Ray ray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f), 0.f};
     V3 thr = v3(1.f, 1.f, 1.f);
     uint32_t segments = 0, rounds = 0;
+#ifdef MIRT_WALK_STATS
+    const long long t_birth = clock64();
+    long long ph0 = 0, ph1 = 0, ph2 = 0;
+#endif
+    Walk wk;               // the lane's walk of the hierarchies, kept from iteration to iteration
+    bool walking = false;  // ... which is not over yet
+    uint32_t walk_n = 0;
+    const uint32_t walk_budget = a.walk_budget;
+    wk.ref = kWalkIdle;
+    wk.next = wk.sp = 0;
 
     // Gives the lanes with `need` their next pixel: position, first sample, empty sums. Indices of the edge
     // tiles that lie outside the frame are skipped. A lane that gets none is done (alive = false).
@@ -272,31 +282,44 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     // argument block would move it to memory and turn every scene read into a per-lane load)
     uint32_t* const work_counter = a.work_counter;
     float4* const accum = a.accum;
-    const uint32_t width = a.width, height = a.height, spp_begin = a.spp_begin;
+    const uint32_t width = a.width, height = a.height, spp_begin = a.spp_begin, spp_last = a.spp_begin + a.spp_count;
+    const uint32_t chunk_spp = a.chunk_spp, n_chunks = a.n_chunks, n_pixels = a.width * a.height;
     const float spp_count = (float)a.spp_count;
-    auto next_pixel = [&q, &alive, &x, &y, &pixel, &sample, &acc, work_counter, total, tiles_x, width, height, spp_begin](bool need) {
+    float4* const partial = a.partial;
+    auto next_pixel = [&q, &alive, &x, &y, &pixel, &sample, &sample_end, &slot, &acc, work_counter, total, per_chunk, tiles_x, width,
+                       height, spp_begin, spp_last, chunk_spp, n_pixels](bool need) {
         for (;;) {
             if (__ballot(need) == 0) break;
             const uint32_t idx = take_pixels(need, q, work_counter, total);
             if (need) {
                 alive = idx != 0xffffffffu;
                 if (alive) {
-                    const uint32_t tile = idx >> 6, in = idx & 63u;
+                    const uint32_t chunk = idx / per_chunk, rest = idx - chunk * per_chunk;
+                    const uint32_t tile = rest >> 6, in = rest & 63u;
                     x = (tile % tiles_x) * 8u + (in & 7u);
                     y = (tile / tiles_x) * 8u + (in >> 3);
                     pixel = y * width + x;
-                    sample = spp_begin;
+                    slot = chunk * n_pixels + pixel;
+                    sample = spp_begin + chunk * chunk_spp;
+                    sample_end = min(sample + chunk_spp, spp_last);
                     acc = v3(0.f, 0.f, 0.f);
                 }
                 need = alive && !(x < width && y < height);  // outside the frame: take another
             }
         }
     };
-    // The lane's pixel has all its samples: renderer.rs:107-110 for the whole pixel.
-    auto flush_pixel = [&pixel, &acc, accum, spp_count]() {
-        float4 v = accum[pixel];
-        v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += spp_count;
-        accum[pixel] = v;
+    // The lane's work item has all its samples (renderer.rs:107-110). With one chunk per pixel the sums go
+    // straight to the accumulation buffer; otherwise to the item's own slot, and reduce_chunks_kernel adds
+    // the slots of a pixel in chunk order — no floating-point atomics, so the result does not depend on
+    // which lane rendered what, or when.
+    auto flush_pixel = [&pixel, &slot, &acc, accum, partial, spp_count, n_chunks]() {
+        if (n_chunks == 1u) {
+            float4 v = accum[pixel];
+            v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += spp_count;
+            accum[pixel] = v;
+        } else {
+            partial[slot] = make_float4(acc.x, acc.y, acc.z, 0.f);
+        }
     };
 
     next_pixel(true);
@@ -307,10 +330,49 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     }
     while (__ballot(alive) != 0) {
         ++rounds;
-        // ---- trace: scene.world.hit (renderer.rs:201)
+        // ---- trace: scene.world.hit (renderer.rs:201). The lists are scanned in the iteration that starts
+        //      the segment; the hierarchies are walked a bounded number of steps per iteration, and a lane
+        //      whose walk is not over sits out the rest of the iteration and continues in the next one.
         float t = MIRT_INF;
         int prim = -1;
-        if (alive) {
+        bool ready = alive;
+#ifdef MIRT_WALK_STATS
+        const long long tc0 = clock64();
+        long long tc1 = tc0, tc2 = tc0;
+#endif
+        if constexpr ((FT & F_BVH) != 0) {
+            if (alive && !walking) {
+                DrawKey key{pixel, sample, bounce, a.seed};
+                wk.closest = MIRT_INF;
+                wk.best = -1;
+                world_lists<FT>(a.scene, ray, key, wk.closest, wk.best);
+                wk.next = 0;
+                wk.ref = kWalkIdle;
+                walk_n = walk_count(a.scene, ray);
+                ++segments;
+            }
+#ifdef MIRT_WALK_STATS
+            tc1 = clock64();
+            uint32_t wsteps = 0;
+            if (alive) walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, stack, kBlock, wsteps);
+            tc2 = clock64();
+#ifndef MIRT_PHASE_ONLY
+            {
+                auto bin = [](uint32_t v) { return v < 8 ? 0u : v < 16 ? 1u : v < 32 ? 2u : v < 64 ? 3u : v < 128 ? 4u : v < 256 ? 5u : 6u; };
+                uint32_t mx = wsteps;
+                for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off));
+                if (alive) atomicAdd(&g_walk_hist[bin(wsteps)], 1ull);
+                if (alive) atomicAdd(&g_walk_hist[14], (unsigned long long)wsteps);
+                if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_walk_hist[7 + bin(mx)], 1ull); atomicAdd(&g_walk_hist[15], (unsigned long long)mx); }
+            }
+#endif
+#else
+            if (alive) walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, stack, kBlock);
+#endif
+            ready = alive && !walking;
+            t = wk.closest;
+            prim = wk.best;
+        } else if (alive) {
             DrawKey key{pixel, sample, bounce, a.seed};
             world_hit<FT>(a.scene, ray, key, stack, kBlock, t, prim);
             ++segments;
@@ -319,7 +381,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         HitInfo h;
         DevShade m;
         bool ended = false;
-        if (alive) {
+        if (ready) {
             V3 e = v3(0.f, 0.f, 0.f);
             if (prim < 0) {
                 e = cmul(thr, v3(a.scene.background));  // renderer.rs:233-235
@@ -339,7 +401,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         }
         // ---- pixels that are complete go out, their lanes take the next pixel of the launch
         {
-            const bool done = alive && ended && sample == sample_end;
+            const bool done = ready && ended && sample == sample_end;
             if (__ballot(done) != 0) {
                 if (done) flush_pixel();
                 next_pixel(done);
@@ -355,7 +417,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         g.init_with_block0(pixel, sample, r_bounce, r_stream, a.seed, w0, w1, w2, w3);
 
         bool over = false;  // path closed after its scatter draws: needs a camera ray from a fresh stream
-        if (alive && !ended) {
+        if (ready && alive && !ended) {
             const bool cont = scatter<F>(a.scene, tb, m, h, g, ray, thr);
             --depth_left;
             ++bounce;
@@ -363,7 +425,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 ++sample;
                 over = true;
             }
-        } else if (alive) {
+        } else if (ready && alive) {
             ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, g);
             thr = v3(1.f, 1.f, 1.f);
             depth_left = a.max_depth;
@@ -384,7 +446,21 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 bounce = 0;
             }
         }
+#ifdef MIRT_WALK_STATS
+        {
+            const long long tc3 = clock64();
+            ph0 += tc1 - tc0; ph1 += tc2 - tc1; ph2 += tc3 - tc2;
+        }
+#endif
     }
+#ifdef MIRT_WALK_STATS
+    if ((threadIdx.x & 63u) == 0) {
+        const unsigned long long life = (unsigned long long)(clock64() - t_birth);
+        atomicAdd(&g_life[0], life); atomicMax(&g_life[1], life); atomicAdd(&g_life[2], 1ull);
+        atomicAdd(&g_phase[0], (unsigned long long)ph0); atomicAdd(&g_phase[1], (unsigned long long)ph1);
+        atomicAdd(&g_phase[2], (unsigned long long)ph2); atomicAdd(&g_phase[3], (unsigned long long)rounds);
+    }
+#endif
     for (int off = 32; off > 0; off >>= 1) segments += __shfl_down(segments, off);
     if ((threadIdx.x & 63u) == 0 && a.segment_counter) {
         atomicAdd(a.segment_counter, (unsigned long long)segments);
@@ -396,6 +472,20 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
 __global__ __launch_bounds__(kBlock) void count_samples_kernel(float4* accum, uint32_t n, float spp) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i < n) accum[i].w += spp;
+}
+
+// Second step of a persistent launch that split every pixel's samples into chunks: the chunk sums of a
+// pixel, in chunk order, onto the accumulation buffer.
+__global__ __launch_bounds__(kBlock) void reduce_chunks_kernel(float4* accum, const float4* partial, uint32_t n, uint32_t n_chunks, float spp) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 v = accum[i];
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+        const float4 p = partial[(size_t)c * n + i];
+        v.x += p.x; v.y += p.y; v.z += p.z;
+    }
+    v.w += spp;
+    accum[i] = v;
 }
 
 template <uint32_t F>
@@ -510,10 +600,15 @@ static hipError_t launch_persistent(Kernel kernel, const RenderArgs& a, hipStrea
     if (e != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0)) != hipSuccess) return e;
-    const uint32_t pixels = ((a.width + 7u) / 8u) * ((a.height + 7u) / 8u) * 64u;
-    const uint32_t want = (pixels + kBlock - 1) / kBlock;
+    const uint64_t items = (uint64_t)((a.width + 7u) / 8u) * ((a.height + 7u) / 8u) * 64u * a.n_chunks;
+    if (a.n_chunks == 0 || items >= 0xffffff00ull || (a.n_chunks > 1 && !a.partial)) return hipErrorInvalidValue;
+    const uint32_t want = (uint32_t)((items + kBlock - 1) / kBlock);
     const uint32_t resident = (uint32_t)std::max(cus * per_cu, 1);
     hipLaunchKernelGGL(kernel, dim3(std::min(want, resident)), dim3(kBlock), 0, stream, a);
+    if ((e = hipGetLastError()) != hipSuccess || a.n_chunks == 1) return e;
+    const uint32_t n = a.width * a.height;
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a.accum, a.partial, n, a.n_chunks,
+                       (float)a.spp_count);
     return hipGetLastError();
 }
 
@@ -525,9 +620,10 @@ struct RenderLauncher {
         const bool lds = s.n_prims <= kLdsPrims && s.n_instances <= kLdsInstances && s.n_lights <= kLdsLights;
         const bool pinhole = a.cam.lens_radius == 0.f && !(s.features & F_MOVING);
         dim3 grid(tiles), block(kBlock);
-        // Which loop: scenes with a hierarchy have paths of very unequal cost and gain 8-16 % from the pixel
-        // queue; the list scenes are VALU-issue bound, their lanes are 92 % busy already, and the queue's
-        // bookkeeping costs them more than the idle lanes it recovers (Cornell 11.1 against 13.2 Gsamples/s).
+        // Which loop: the persistent kernel unless the caller asks for the other. Its (pixel, sample chunk)
+        // items keep every wave busy until the launch ends, where the one-pixel-per-lane kernel waits for
+        // the most expensive tile of the launch and, inside a wave, for the most expensive pixel of the
+        // tile (measured at 1080p: Cornell 13.3 -> 15.6 Gsamples/s, `final` 0.80 -> 1.44).
         if (render_uses_queue(a)) {
             if (a.max_depth == 0) {
                 const uint32_t n = a.width * a.height;
@@ -562,12 +658,23 @@ struct RayColorLauncher {
     }
 };
 
+#ifdef MIRT_WALK_STATS
+extern "C" void mirt_debug_walk_hist(unsigned long long* out) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_walk_hist), sizeof(g_walk_hist));
+    (void)hipMemcpyFromSymbol(out + 16, HIP_SYMBOL(g_phase), sizeof(g_phase));
+    (void)hipMemcpyFromSymbol(out + 20, HIP_SYMBOL(g_life), sizeof(g_life));
+    { unsigned long long z4[4] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_life), z4, sizeof(z4)); }
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_walk_hist), z, sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(g_phase));
+}
+#endif
 bool render_uses_queue(const RenderArgs& a) {
     // the environment variable overrides an AUTO choice for A/B runs of whole programs
     static const int env = [] { const char* e = std::getenv("MIRT_QUEUE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (!a.work_counter || a.loop == LOOP_FUSED) return false;
     if (a.loop == LOOP_QUEUE) return true;
-    return env >= 0 ? env == 1 : (a.scene.features & F_BVH) != 0;
+    return env >= 0 ? env == 1 : true;
 }
 hipError_t launch_render_fused(const RenderArgs& a, hipStream_t stream) {
     if (a.width == 0 || a.height == 0 || a.spp_count == 0) return hipSuccess;

@@ -34,6 +34,9 @@ struct mirt_ctx {
     uint32_t width = 0, height = 0;
     uint8_t* frame_dev = nullptr;
     size_t frame_dev_bytes = 0;
+    uint32_t n_bvh_nodes = 0;                   // nodes of all hierarchies of the scene
+    float4* partial = nullptr;                  // chunk sums of the persistent kernel (grown on demand)
+    size_t partial_bytes = 0;
     unsigned long long* seg_counter = nullptr;  // kCounters device counters: segments, lane slots
     mirt_stats stats{};
     // wavefront kernel set: path state + queues for `wf_capacity` slots, counters mirrored in pinned memory
@@ -182,6 +185,7 @@ void mirt_destroy(mirt_ctx* c) {
     if (c->accum_owned) (void)hipFree(c->accum_owned);
     if (c->frame_dev) (void)hipFree(c->frame_dev);
     if (c->seg_counter) (void)hipFree(c->seg_counter);
+    if (c->partial) (void)hipFree(c->partial);
     for (void* p : c->wf_allocs) (void)hipFree(p);
     if (c->wf_counts_host) (void)hipHostFree(c->wf_counts_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -522,6 +526,7 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     if ((rc = upload(c, perlins, &s.perlins))) return rc;
     if ((rc = upload(c, insts, &s.instances))) return rc;
     if ((rc = upload(c, nodes, &s.bvh_nodes))) return rc;
+    c->n_bvh_nodes = (uint32_t)nodes.size();
     if ((rc = upload(c, leaves, &s.bvh_leaves))) return rc;
     std::vector<uint32_t> bvh_entries;
     for (uint32_t e = 0; e < d->n_world; ++e)
@@ -689,15 +694,54 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     a.segment_counter = c->seg_counter;
     a.work_counter = reinterpret_cast<uint32_t*>(c->seg_counter + kCounters);
     a.loop = p->kernel == MIRT_KERNEL_FUSED ? LOOP_FUSED : (p->kernel == MIRT_KERNEL_QUEUE ? LOOP_QUEUE : LOOP_AUTO);
+    {
+        static const uint32_t budget = [] {
+            const char* e = std::getenv("MIRT_WALK_BUDGET");
+            const long v = e ? std::atol(e) : 0;
+            return v > 0 ? (uint32_t)v : 0u;
+        }();
+        // Deep hierarchies have walks of very unequal length (1 M spheres: 33 steps on average, 93 for the
+        // longest lane of a wave) and gain 30 % from short turns; on small ones a turn that cuts walks short
+        // only repeats the list scan and shading code of the iteration (measured: `final` 1 440 Msamples/s
+        // with 48 steps or unbounded, 1 340 with 24).
+        a.walk_budget = budget ? budget : (c->n_bvh_nodes >= 65536u ? 24u : 48u);
+    }
     // Long renders are cut into launches of at most kChunk samples per pixel: lanes of a wave
     // then finish within a few percent of each other and no launch runs for seconds.
     uint32_t kChunk = 1024;  // measured on Cornell 1080p: 64 -> 9.5, 256 -> 10.6, 1024 -> 11.2 Gsamples/s (fewer launch tails)
     if (const char* env = std::getenv("MIRT_CHUNK_SPP")) { int v = std::atoi(env); if (v > 0) kChunk = (uint32_t)v; }
+    static const uint32_t split = [] {
+        const char* e = std::getenv("MIRT_SPLIT");
+        const long v = e ? std::atol(e) : 0;
+        return v > 0 ? (uint32_t)std::min(v, 1024l) : 16u;
+    }();
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     uint32_t launches = 0;
     for (uint32_t done = 0; done < p->spp_count; done += kChunk) {
         a.spp_begin = p->spp_begin + done;
         a.spp_count = std::min(kChunk, p->spp_count - done);
+        a.n_chunks = 1;
+        a.chunk_spp = a.spp_count;
+        if (render_uses_queue(a) && a.max_depth > 0 && split > 1 && a.spp_count > 1) {
+            // The persistent kernel hands out (pixel, sample chunk) items: with whole pixels as items the launch
+            // lasts as long as its most expensive pixel (measured on `final`: the average wave was alive for 46 %
+            // of the kernel's duration, the rest was the tail of the pixels on the sphere cluster).
+            a.chunk_spp = (a.spp_count + split - 1) / split;
+            a.n_chunks = (a.spp_count + a.chunk_spp - 1) / a.chunk_spp;
+            const uint64_t items = (uint64_t)(((a.width + 7u) / 8u) * ((a.height + 7u) / 8u)) * 64u * a.n_chunks;
+            const size_t bytes = (size_t)a.n_chunks * a.width * a.height * sizeof(float4);
+            if (items >= 0xffffff00ull) {
+                a.n_chunks = 1;
+                a.chunk_spp = a.spp_count;
+            } else if (a.n_chunks > 1 && bytes > c->partial_bytes) {
+                if (c->partial) HIP_TRY(c, hipFree(c->partial));
+                c->partial = nullptr;
+                c->partial_bytes = 0;
+                HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->partial), bytes));
+                c->partial_bytes = bytes;
+            }
+        }
+        a.partial = c->partial;
         HIP_TRY(c, hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), c->stream));
         HIP_TRY(c, launch_render_fused(a, c->stream));
         ++launches;

@@ -15,7 +15,7 @@ import csv, glob, collections
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob("$OUT/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "render_fused" in r["Kernel_Name"]:
-            tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+        if "render_" in r["Kernel_Name"] or "reduce_chunks" in r["Kernel_Name"]:
+            key = r["Counter_Name"] + " " + r["Kernel_Name"].split("<")[0].split("(")[0][-24:]; tot[key] += float(r["Counter_Value"]); n[key] += 1
 for k in sorted(tot): print(k, "sum", tot[k], "dispatch rows", n[k])
 PY

@@ -422,24 +422,36 @@ def test_ragged_frame_sizes(rt, oracle, earth, w, h):
 @pytest.mark.parametrize("name,spp,size", [("cornell", 24, (64, 36)), ("smoke", 8, (64, 36)), ("random", 8, (64, 36)),
                                            ("final", 4, (64, 36)), ("2psp", 8, (37, 19)), ("random", 3, (130, 70))])
 def test_pixel_queue_kernel_equals_fused_kernel(rt, oracle, earth, name, spp, size):
-    """The persistent kernel (lanes draw pixels from a shared counter) renders every pixel in one lane, sample
-    after sample, exactly as the one-pixel-per-lane kernel does: the sums are equal bit for bit, whichever lane
-    took which pixel, and so are the segment counts. AUTO picks it for scenes with a hierarchy."""
+    """The persistent kernel hands (pixel, sample chunk) items to its lanes from a shared counter. Every sample
+    is the same path as in the one-pixel-per-lane kernel (equal segment counts); a chunk's samples are added
+    in order by one lane and the chunk sums of a pixel in chunk order, so the result does not depend on which
+    lane took what and differs from the other kernel's only by the regrouping of the float additions. With one
+    sample per call there is one chunk and the sums are equal bit for bit. AUTO picks the persistent
+    kernel."""
     w, h = size
     orc, ctx, _ = make(rt, oracle, earth, name, w, h)
     out = {}
-    for kernel in (rt.KERNEL_FUSED, rt.KERNEL_QUEUE, rt.KERNEL_AUTO):
+    for kernel in (rt.KERNEL_FUSED, rt.KERNEL_QUEUE, rt.KERNEL_AUTO, "queue again"):
+        k = rt.KERNEL_QUEUE if kernel == "queue again" else kernel
         ctx.frame_begin(w, h)
-        ctx.render(spp, 50, seed=8, kernel=kernel)
-        ctx.render(2, 50, spp_begin=spp, seed=8, kernel=kernel)     # a second sample range on top
+        ctx.render(spp, 50, seed=8, kernel=k)
+        ctx.render(2, 50, spp_begin=spp, seed=8, kernel=k)     # a second sample range on top
         st = ctx.stats()
         out[kernel] = (ctx.read_accum(), st["segments"], st["kernel_used"])
     assert out[rt.KERNEL_FUSED][2] == rt.KERNEL_FUSED and out[rt.KERNEL_QUEUE][2] == rt.KERNEL_QUEUE
-    assert out[rt.KERNEL_AUTO][2] == (rt.KERNEL_QUEUE if name in ("random", "final") else rt.KERNEL_FUSED)
-    assert (out[rt.KERNEL_QUEUE][0] == out[rt.KERNEL_FUSED][0]).all()
-    assert (out[rt.KERNEL_AUTO][0] == out[rt.KERNEL_FUSED][0]).all()
+    assert out[rt.KERNEL_AUTO][2] == rt.KERNEL_QUEUE
+    np.testing.assert_allclose(out[rt.KERNEL_QUEUE][0], out[rt.KERNEL_FUSED][0], rtol=2e-6, atol=1e-6)
+    np.testing.assert_allclose(out[rt.KERNEL_AUTO][0], out[rt.KERNEL_FUSED][0], rtol=2e-6, atol=1e-6)
+    assert (out["queue again"][0] == out[rt.KERNEL_QUEUE][0]).all()      # scheduling does not enter the sums
     assert out[rt.KERNEL_QUEUE][1] == out[rt.KERNEL_FUSED][1]
-    assert (out[rt.KERNEL_FUSED][0][..., 3] == spp + 2).all()
+    assert (out[rt.KERNEL_FUSED][0][..., 3] == spp + 2).all() and (out[rt.KERNEL_QUEUE][0][..., 3] == spp + 2).all()
+    one = {}
+    for kernel in (rt.KERNEL_FUSED, rt.KERNEL_QUEUE):
+        ctx.frame_begin(w, h)
+        for k in range(3):
+            ctx.render(1, 50, spp_begin=k, seed=8, kernel=kernel)
+        one[kernel] = ctx.read_accum()
+    assert (one[rt.KERNEL_QUEUE] == one[rt.KERNEL_FUSED]).all()
 
 
 def _sphere_scene(rt, centres, radius, entry_kind):
