@@ -558,21 +558,11 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
 // the walk is complete. A render loop that calls this once per iteration lets the lanes whose walk is
 // over shade and start their next segment while a lane with a long walk (a ray through a dense cluster)
 // keeps its place and goes on in the next iteration, instead of the whole wave waiting for it.
-#ifdef MIRT_WALK_STATS
-static __device__ unsigned long long g_walk_hist[16];
-static __device__ unsigned long long g_phase[4];
-static __device__ unsigned long long g_life[4];
-static __device__ uint32_t g_walk_steps_dummy;
-#define g_walk_steps walk_steps_out
-#endif
+// `steps` receives the number of steps taken (statistics builds read it; otherwise it folds away).
 template <uint32_t F>
 MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t* stack,
-                        uint32_t stride
-#ifdef MIRT_WALK_STATS
-                        , uint32_t& walk_steps_out
-#endif
-                        ) {
-    uint32_t steps = 0;
+                        uint32_t stride, uint32_t& steps) {
+    steps = 0;
     for (;;) {
         if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w);
         while (w.ref != kWalkIdle && steps < budget) {
@@ -587,9 +577,6 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
         }
         if (w.ref != kWalkIdle || w.next >= n) break;  // out of budget, or every hierarchy walked
     }
-#ifdef MIRT_WALK_STATS
-    g_walk_steps = steps;
-#endif
     return w.ref == kWalkIdle;
 }
 

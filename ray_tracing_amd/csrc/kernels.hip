@@ -33,6 +33,39 @@ constexpr int waves_for(uint32_t features) {
     return (features & (F_TEX_NOISE | F_TEX_IMAGE)) ? MIRT_WAVES_TEX : ((features & F_BVH) ? MIRT_WAVES_BVH : MIRT_WAVES);
 }
 
+// Statistics build (-DMIRT_WALK_STATS, read out by scripts/walk_hist.py through mirt_debug_walk_hist): per
+// iteration of the persistent kernel the shader clocks spent in the list scans, the hierarchy walk and the
+// rest (lane 0 of every wave), the lifetime of every wave against the longest one (how much of the launch
+// is its tail), and histograms of the hierarchy steps per lane and of the longest lane of the wave. The
+// histogram atomics slow the kernel several times: -DMIRT_PHASE_ONLY leaves them out for the clock figures.
+#ifdef MIRT_WALK_STATS
+#define MIRT_STATS(...) __VA_ARGS__
+static __device__ unsigned long long g_walk_hist[16];  // [0..6] lanes by steps, [7..13] waves by longest lane, [14] / [15] sums
+static __device__ unsigned long long g_phase[4];       // clocks: lists, walk, shading; [3] wave iterations
+static __device__ unsigned long long g_life[4];        // sum of wave lifetimes, longest, number of waves
+__device__ __forceinline__ void walk_histogram(bool alive, uint32_t steps) {
+#ifndef MIRT_PHASE_ONLY
+    auto bin = [](uint32_t v) { return v < 8 ? 0u : v < 16 ? 1u : v < 32 ? 2u : v < 64 ? 3u : v < 128 ? 4u : v < 256 ? 5u : 6u; };
+    uint32_t mx = steps;
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off));
+    if (alive) atomicAdd(&g_walk_hist[bin(steps)], 1ull);
+    if (alive) atomicAdd(&g_walk_hist[14], (unsigned long long)steps);
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(&g_walk_hist[7 + bin(mx)], 1ull);
+        atomicAdd(&g_walk_hist[15], (unsigned long long)mx);
+    }
+#endif
+}
+__device__ __forceinline__ void wave_totals(long long life, long long lists, long long walk, long long shade, uint32_t rounds) {
+    if ((threadIdx.x & 63u) != 0) return;
+    atomicAdd(&g_life[0], (unsigned long long)life); atomicMax(&g_life[1], (unsigned long long)life); atomicAdd(&g_life[2], 1ull);
+    atomicAdd(&g_phase[0], (unsigned long long)lists); atomicAdd(&g_phase[1], (unsigned long long)walk);
+    atomicAdd(&g_phase[2], (unsigned long long)shade); atomicAdd(&g_phase[3], (unsigned long long)rounds);
+}
+#else
+#define MIRT_STATS(...)
+#endif
+
 // capacity of the per-block LDS copies of the tables shading indexes per lane
 constexpr uint32_t kLdsPrims = 64, kLdsInstances = 16, kLdsLights = 8;
 
@@ -197,7 +230,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(Rend
 // finish. A pixel is rendered by exactly one lane, sample after sample, so the sums are the ones of the
 // kernel above, bit for bit.
 struct PixelQueue {
-    uint32_t pos, end;  // the wave's current run of pixel indices (wave-uniform)
+    uint32_t pos, end;  // the wave's current run of item indices (wave-uniform)
     bool drained;       // the global counter has passed the last index
 };
 
@@ -210,15 +243,20 @@ __device__ __forceinline__ uint32_t take_pixels(bool need, PixelQueue& q, uint32
         if (m == 0) break;
         if (q.pos == q.end) {
             if (q.drained) break;
+            // One wave-load per trip to the counter. Longer runs (fixed, or a share of what is left) were
+            // measured: they only pay on scenes with almost free samples (one sphere: 21 -> 48 Gsamples/s at
+            // 256 items), and cost 3-50 % elsewhere, because neighbouring items cost alike and a wave that
+            // holds a long run of expensive ones becomes the tail of the launch.
+            constexpr uint32_t run = 64u;
             uint32_t c = 0;
-            if (lane == 0) c = atomicAdd(counter, 64u);
+            if (lane == 0) c = atomicAdd(counter, run);
             c = __builtin_amdgcn_readfirstlane(c);
             if (c >= total) {
                 q.drained = true;
                 break;
             }
             q.pos = c;
-            q.end = min(c + 64u, total);
+            q.end = min(c + run, total);
         }
         const uint32_t avail = q.end - q.pos;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -265,10 +303,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     Ray ray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f), 0.f};
     V3 thr = v3(1.f, 1.f, 1.f);
     uint32_t segments = 0, rounds = 0;
-#ifdef MIRT_WALK_STATS
-    const long long t_birth = clock64();
-    long long ph0 = 0, ph1 = 0, ph2 = 0;
-#endif
+    MIRT_STATS(const long long t_birth = clock64(); long long ph0 = 0, ph1 = 0, ph2 = 0);
     Walk wk;               // the lane's walk of the hierarchies, kept from iteration to iteration
     bool walking = false;  // ... which is not over yet
     uint32_t walk_n = 0;
@@ -336,10 +371,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         float t = MIRT_INF;
         int prim = -1;
         bool ready = alive;
-#ifdef MIRT_WALK_STATS
-        const long long tc0 = clock64();
-        long long tc1 = tc0, tc2 = tc0;
-#endif
+        MIRT_STATS(const long long tc0 = clock64(); long long tc1 = tc0, tc2 = tc0);
         if constexpr ((FT & F_BVH) != 0) {
             if (alive && !walking) {
                 DrawKey key{pixel, sample, bounce, a.seed};
@@ -351,24 +383,11 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 walk_n = walk_count(a.scene, ray);
                 ++segments;
             }
-#ifdef MIRT_WALK_STATS
-            tc1 = clock64();
             uint32_t wsteps = 0;
+            MIRT_STATS(tc1 = clock64());
             if (alive) walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, stack, kBlock, wsteps);
-            tc2 = clock64();
-#ifndef MIRT_PHASE_ONLY
-            {
-                auto bin = [](uint32_t v) { return v < 8 ? 0u : v < 16 ? 1u : v < 32 ? 2u : v < 64 ? 3u : v < 128 ? 4u : v < 256 ? 5u : 6u; };
-                uint32_t mx = wsteps;
-                for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor(mx, off));
-                if (alive) atomicAdd(&g_walk_hist[bin(wsteps)], 1ull);
-                if (alive) atomicAdd(&g_walk_hist[14], (unsigned long long)wsteps);
-                if ((threadIdx.x & 63u) == 0) { atomicAdd(&g_walk_hist[7 + bin(mx)], 1ull); atomicAdd(&g_walk_hist[15], (unsigned long long)mx); }
-            }
-#endif
-#else
-            if (alive) walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, stack, kBlock);
-#endif
+            MIRT_STATS(tc2 = clock64());
+            MIRT_STATS(walk_histogram(alive, wsteps));
             ready = alive && !walking;
             t = wk.closest;
             prim = wk.best;
@@ -446,21 +465,9 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 bounce = 0;
             }
         }
-#ifdef MIRT_WALK_STATS
-        {
-            const long long tc3 = clock64();
-            ph0 += tc1 - tc0; ph1 += tc2 - tc1; ph2 += tc3 - tc2;
-        }
-#endif
+        MIRT_STATS(const long long tc3 = clock64(); ph0 += tc1 - tc0; ph1 += tc2 - tc1; ph2 += tc3 - tc2);
     }
-#ifdef MIRT_WALK_STATS
-    if ((threadIdx.x & 63u) == 0) {
-        const unsigned long long life = (unsigned long long)(clock64() - t_birth);
-        atomicAdd(&g_life[0], life); atomicMax(&g_life[1], life); atomicAdd(&g_life[2], 1ull);
-        atomicAdd(&g_phase[0], (unsigned long long)ph0); atomicAdd(&g_phase[1], (unsigned long long)ph1);
-        atomicAdd(&g_phase[2], (unsigned long long)ph2); atomicAdd(&g_phase[3], (unsigned long long)rounds);
-    }
-#endif
+    MIRT_STATS(wave_totals(clock64() - t_birth, ph0, ph1, ph2, rounds));
     for (int off = 32; off > 0; off >>= 1) segments += __shfl_down(segments, off);
     if ((threadIdx.x & 63u) == 0 && a.segment_counter) {
         atomicAdd(a.segment_counter, (unsigned long long)segments);

@@ -1,4 +1,4 @@
-"""Throughput of every preset scene at 1920x1080 (spp chosen per scene)."""
+"""Throughput of every preset scene at 1920x1080 (spp chosen per scene) with the three forms of the sample loop."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ray_tracing_amd as rt
@@ -9,11 +9,11 @@ for scene, spp, kw in [("cornell", 256, {}), ("smoke", 64, {}), ("random", 32, {
     ctx = rt.Context(0)
     ctx.scene_upload(sc)
     ctx.camera_set(rt.Camera.select_camera(W / H, scene))
-    for kern in (rt.KERNEL_FUSED, rt.KERNEL_WAVEFRONT):
+    row = []
+    for name, kern in (("queue", rt.KERNEL_QUEUE), ("fused", rt.KERNEL_FUSED), ("wavefront", rt.KERNEL_WAVEFRONT)):
       ctx.frame_begin(W, H)
       ctx.render(spp, 50 if not kw else 10, seed=0, kernel=kern)
       ctx.synchronize()
       st = ctx.stats()
-      print('  kernel', kern, f"kernel_ms={st['kernel_ms']:.1f} Msamples/s={st['samples'] / st['kernel_ms'] / 1e3:.1f} Gseg/s={st['segments'] / st['kernel_ms'] / 1e6:.2f} launches={st['kernel_launches']}", flush=True)
-    print(f"{scene:8s} {kw} prims={sc.desc.n_prims} spp={spp} kernel_ms={st['kernel_ms']:.1f} Msamples/s={st['samples'] / st['kernel_ms'] / 1e3:.1f} "
-          f"Gseg/s={st['segments'] / st['kernel_ms'] / 1e6:.2f} seg/sample={st['segments'] / st['samples']:.2f}", flush=True)
+      row.append(f"{name} {st['samples'] / st['kernel_ms'] / 1e3:.0f}")
+    print(f"{scene:8s} {kw} prims={sc.desc.n_prims} spp={spp} seg/sample={st['segments'] / st['samples']:.2f}  Msamples/s: " + ", ".join(row), flush=True)

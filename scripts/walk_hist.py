@@ -1,3 +1,6 @@
+"""Reads the counters of the statistics build of the library (make -C ray_tracing_amd/csrc stats; run with
+MIRT_LIB=ray_tracing_amd/libmirt_stats.so): hierarchy steps per lane and per wave, shader clocks per phase of an
+iteration, wave lifetimes against the longest wave. CUT=n cuts the sphere cluster of `final` to n spheres."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.getcwd())
 import ray_tracing_amd as rt
