@@ -20,11 +20,12 @@ if ROOT not in sys.path:
 
 FLOP_PER_SEGMENT = 400.0       # algorithmic FLOP of one Cornell path segment (12 rect tests x 12 + sphere 30 +
                                # instance transform 15 + diffuse shade with the 2-light mixture pdf 200)
-# MI355X FP32 vector peak (spec, packed v_pk_fma_f32): the `peak` of the roofline object. Plain v_fma_f32 code
-# issues at half of it (256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s); the render kernel of the
-# list scenes emits no packed arithmetic, so the fraction of that rate is reported beside `frac`.
+# MI355X FP32 vector peak (spec, packed v_pk_fma_f32): the `peak` of the roofline object. Plain v_fma_f32 code was
+# measured at 111.8 TFLOP/s (scripts/calib/valu_count.hip: a wave64 v_fma_f32 per 2.8 cycles and SIMD with 8
+# waves resident); the render kernel is scalar-per-lane code except for the rect pairs, so the fraction of that
+# measured rate is reported beside `frac`.
 PEAK_FP32_VALU_TFLOPS = 157.3
-UNPACKED_FP32_TFLOPS = 78.6
+UNPACKED_FP32_TFLOPS = 111.8
 # HBM bytes of one launch of the render kernel on the default workload, from rocprofv3 PMC passes
 # (profiles/r1/cornell_1080p_1024spp_v3_hbm_traffic_pmc.txt): 2 x FETCH_SIZE (gfx950 counts half of a wide read)
 # + WRITE_SIZE, in KiB. The persistent kernel writes one float4 per pixel and sample chunk (16 chunks x 33.2 MB)

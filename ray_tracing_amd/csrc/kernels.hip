@@ -222,48 +222,57 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(Rend
     finish_pixel(a, valid, pixel, acc, segments, segments);
 }
 
-// The sample loop as a persistent kernel. The grid is only as large as the device holds at once; every
-// wave draws pixels from one global counter, 64 indices at a time (index -> 8x8 tile, pixel within the
-// tile), and a lane that has finished all samples of its pixel adds the sums to the accumulation buffer
-// and takes the next index in the same iteration. Nothing waits for the most expensive pixel of a tile
-// or the most expensive tile of a launch: lanes idle only while the last pixels of the whole launch
-// finish. A pixel is rendered by exactly one lane, sample after sample, so the sums are the ones of the
-// kernel above, bit for bit.
-struct PixelQueue {
-    uint32_t pos, end;  // the wave's current run of item indices (wave-uniform)
-    bool drained;       // the global counter has passed the last index
+// The sample loop as a persistent kernel. The grid is only as large as the device holds at once. The work
+// items are (pixel, chunk of its samples); one global counter hands them out a wave-load at a time — counter
+// value c stands for the 64 pixel slots of 8x8 tile (c mod tiles) in sample chunk (c / tiles) — and a lane
+// that has finished its item stores the sums and takes the next slot in the same iteration. Nothing waits
+// for the most expensive pixel of a tile or the most expensive tile of a launch: lanes idle only while the
+// last items of the whole launch finish. An item is rendered by exactly one lane, sample after sample.
+struct ItemQueue {
+    uint32_t pos;            // slots of the wave's current tile already handed out (64: none left)
+    uint32_t x0, y0, chunk;  // that tile's origin and sample chunk (all wave-uniform)
+    bool drained;            // the global counter has passed the last tile
 };
 
-// Hands a pixel index to every lane with `need` (0xffffffff once the launch has no pixels left).
-__device__ __forceinline__ uint32_t take_pixels(bool need, PixelQueue& q, uint32_t* counter, uint32_t total) {
+// Hands an item to every lane with `need`: pixel position and chunk; false once the launch has none left.
+// One trip to the counter fetches one wave-load. Longer runs (fixed, or a share of what is left) were measured:
+// they only pay on scenes with almost free samples (one sphere: 21 -> 48 Gsamples/s at 256 items), and cost
+// 3-50 % elsewhere, because neighbouring items cost alike and a wave that holds a long run of expensive ones
+// becomes the tail of the launch.
+__device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* counter, uint32_t n_tiles, uint32_t tiles_x,
+                                           uint32_t n_chunks, uint32_t& x, uint32_t& y, uint32_t& chunk) {
     const uint32_t lane = threadIdx.x & 63u;
-    uint32_t idx = 0xffffffffu;
+    bool got = false;
     for (;;) {
-        const unsigned long long m = __ballot(need && idx == 0xffffffffu);
+        const unsigned long long m = __ballot(need && !got);
         if (m == 0) break;
-        if (q.pos == q.end) {
+        if (q.pos == 64u) {
             if (q.drained) break;
-            // One wave-load per trip to the counter. Longer runs (fixed, or a share of what is left) were
-            // measured: they only pay on scenes with almost free samples (one sphere: 21 -> 48 Gsamples/s at
-            // 256 items), and cost 3-50 % elsewhere, because neighbouring items cost alike and a wave that
-            // holds a long run of expensive ones becomes the tail of the launch.
-            constexpr uint32_t run = 64u;
             uint32_t c = 0;
-            if (lane == 0) c = atomicAdd(counter, run);
+            if (lane == 0) c = atomicAdd(counter, 1u);
             c = __builtin_amdgcn_readfirstlane(c);
-            if (c >= total) {
+            if (c >= n_tiles * n_chunks) {
                 q.drained = true;
                 break;
             }
-            q.pos = c;
-            q.end = min(c + run, total);
+            q.chunk = c / n_tiles;  // wave-uniform arithmetic, once per 64 items
+            const uint32_t tile = c - q.chunk * n_tiles, ty = tile / tiles_x;
+            q.y0 = ty * 8u;
+            q.x0 = (tile - ty * tiles_x) * 8u;
+            q.pos = 0;
         }
-        const uint32_t avail = q.end - q.pos;
+        const uint32_t avail = 64u - q.pos;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (need && idx == 0xffffffffu && rank < avail) idx = q.pos + rank;
+        if (need && !got && rank < avail) {
+            const uint32_t in = q.pos + rank;
+            x = q.x0 + (in & 7u);
+            y = q.y0 + (in >> 3);
+            chunk = q.chunk;
+            got = true;
+        }
         q.pos += min((uint32_t)__popcll(m), avail);
     }
-    return idx;
+    return got;
 }
 
 template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
@@ -290,10 +299,9 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     }
 
     const uint32_t tiles_x = (a.width + 7u) / 8u, tiles_y = (a.height + 7u) / 8u;
-    const uint32_t per_chunk = tiles_x * tiles_y * 64u;  // work items of one sample chunk: every pixel slot of every tile
-    const uint32_t total = per_chunk * a.n_chunks;
+    const uint32_t n_tiles = tiles_x * tiles_y;
     const bool jitter = a.jitter != 0;
-    PixelQueue q{0u, 0u, false};
+    ItemQueue q{64u, 0u, 0u, 0u, false};
 
     // the lane's work item (a pixel and a run of its samples) and its path
     uint32_t pixel = 0, x = 0, y = 0, sample = a.spp_begin, sample_end = a.spp_begin, slot = 0;
@@ -306,6 +314,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     MIRT_STATS(const long long t_birth = clock64(); long long ph0 = 0, ph1 = 0, ph2 = 0);
     Walk wk;               // the lane's walk of the hierarchies, kept from iteration to iteration
     bool walking = false;  // ... which is not over yet
+    bool closed = false;   // the lane's path ended in its last scatter; no ray to trace this iteration
     uint32_t walk_n = 0;
     const uint32_t walk_budget = a.walk_budget;
     wk.ref = kWalkIdle;
@@ -321,18 +330,15 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     const uint32_t chunk_spp = a.chunk_spp, n_chunks = a.n_chunks, n_pixels = a.width * a.height;
     const float spp_count = (float)a.spp_count;
     float4* const partial = a.partial;
-    auto next_pixel = [&q, &alive, &x, &y, &pixel, &sample, &sample_end, &slot, &acc, work_counter, total, per_chunk, tiles_x, width,
+    auto next_pixel = [&q, &alive, &x, &y, &pixel, &sample, &sample_end, &slot, &acc, work_counter, n_tiles, tiles_x, n_chunks, width,
                        height, spp_begin, spp_last, chunk_spp, n_pixels](bool need) {
         for (;;) {
             if (__ballot(need) == 0) break;
-            const uint32_t idx = take_pixels(need, q, work_counter, total);
+            uint32_t chunk = 0;
+            const bool got = take_items(need, q, work_counter, n_tiles, tiles_x, n_chunks, x, y, chunk);
             if (need) {
-                alive = idx != 0xffffffffu;
+                alive = got;
                 if (alive) {
-                    const uint32_t chunk = idx / per_chunk, rest = idx - chunk * per_chunk;
-                    const uint32_t tile = rest >> 6, in = rest & 63u;
-                    x = (tile % tiles_x) * 8u + (in & 7u);
-                    y = (tile / tiles_x) * 8u + (in >> 3);
                     pixel = y * width + x;
                     slot = chunk * n_pixels + pixel;
                     sample = spp_begin + chunk * chunk_spp;
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         bool ready = alive;
         MIRT_STATS(const long long tc0 = clock64(); long long tc1 = tc0, tc2 = tc0);
         if constexpr ((FT & F_BVH) != 0) {
-            if (alive && !walking) {
+            if (alive && !walking && !closed) {
                 DrawKey key{pixel, sample, bounce, a.seed};
                 wk.closest = MIRT_INF;
                 wk.best = -1;
@@ -385,13 +391,13 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
             }
             uint32_t wsteps = 0;
             MIRT_STATS(tc1 = clock64());
-            if (alive) walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, stack, kBlock, wsteps);
+            if (alive && !closed) walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, stack, kBlock, wsteps);
             MIRT_STATS(tc2 = clock64());
             MIRT_STATS(walk_histogram(alive, wsteps));
             ready = alive && !walking;
             t = wk.closest;
             prim = wk.best;
-        } else if (alive) {
+        } else if (alive && !closed) {
             DrawKey key{pixel, sample, bounce, a.seed};
             world_hit<FT>(a.scene, ray, key, stack, kBlock, t, prim);
             ++segments;
@@ -400,7 +406,10 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         HitInfo h;
         DevShade m;
         bool ended = false;
-        if (ready) {
+        if (ready && closed) {
+            ended = true;  // closed by its last scatter (sample already counted): straight to the next sample
+            closed = false;
+        } else if (ready) {
             V3 e = v3(0.f, 0.f, 0.f);
             if (prim < 0) {
                 e = cmul(thr, v3(a.scene.background));  // renderer.rs:233-235
@@ -435,35 +444,23 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         Rng g;
         g.init_with_block0(pixel, sample, r_bounce, r_stream, a.seed, w0, w1, w2, w3);
 
-        bool over = false;  // path closed after its scatter draws: needs a camera ray from a fresh stream
         if (ready && alive && !ended) {
             const bool cont = scatter<F>(a.scene, tb, m, h, g, ray, thr);
             --depth_left;
             ++bounce;
-            if (!cont || depth_left == 0) {  // absorbed, or renderer.rs:198-200: the next level returns 0
+            // absorbed, or renderer.rs:198-200: the next level returns 0. The sample is complete; its lane sits
+            // out the trace of the next iteration and gets there what every path that ends gets: the item
+            // check and a camera ray from that iteration's Philox block. (Doing both here instead means a
+            // second Philox block and camera ray issued for the one or two lanes of a wave in this state.)
+            if (!cont || depth_left == 0) {
                 ++sample;
-                over = true;
+                closed = true;
             }
         } else if (ready && alive) {
             ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, g);
             thr = v3(1.f, 1.f, 1.f);
             depth_left = a.max_depth;
             bounce = 0;
-        }
-        if (__ballot(over) != 0) {
-            const bool done = over && sample == sample_end;
-            if (__ballot(done) != 0) {
-                if (done) flush_pixel();
-                next_pixel(done);
-            }
-            if (over && alive) {
-                Rng gc;
-                gc.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
-                ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, gc);
-                thr = v3(1.f, 1.f, 1.f);
-                depth_left = a.max_depth;
-                bounce = 0;
-            }
         }
         MIRT_STATS(const long long tc3 = clock64(); ph0 += tc1 - tc0; ph1 += tc2 - tc1; ph2 += tc3 - tc2);
     }
@@ -608,7 +605,9 @@ static hipError_t launch_persistent(Kernel kernel, const RenderArgs& a, hipStrea
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0)) != hipSuccess) return e;
     const uint64_t items = (uint64_t)((a.width + 7u) / 8u) * ((a.height + 7u) / 8u) * 64u * a.n_chunks;
-    if (a.n_chunks == 0 || items >= 0xffffff00ull || (a.n_chunks > 1 && !a.partial)) return hipErrorInvalidValue;
+    if (a.n_chunks == 0 || items >= 0xffffff00ull || (uint64_t)a.n_chunks * a.width * a.height >= 0xffffffffull ||
+        (a.n_chunks > 1 && !a.partial))
+        return hipErrorInvalidValue;
     const uint32_t want = (uint32_t)((items + kBlock - 1) / kBlock);
     const uint32_t resident = (uint32_t)std::max(cus * per_cu, 1);
     hipLaunchKernelGGL(kernel, dim3(std::min(want, resident)), dim3(kBlock), 0, stream, a);

@@ -730,7 +730,7 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
             a.n_chunks = (a.spp_count + a.chunk_spp - 1) / a.chunk_spp;
             const uint64_t items = (uint64_t)(((a.width + 7u) / 8u) * ((a.height + 7u) / 8u)) * 64u * a.n_chunks;
             const size_t bytes = (size_t)a.n_chunks * a.width * a.height * sizeof(float4);
-            if (items >= 0xffffff00ull) {
+            if (items >= 0xffffff00ull || (uint64_t)a.n_chunks * a.width * a.height >= 0xffffffffull) {
                 a.n_chunks = 1;
                 a.chunk_spp = a.spp_count;
             } else if (a.n_chunks > 1 && bytes > c->partial_bytes) {
