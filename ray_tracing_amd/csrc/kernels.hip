@@ -402,6 +402,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
             world_hit<FT>(a.scene, ray, key, stack, kBlock, t, prim);
             ++segments;
         }
+        if constexpr ((FT & F_BVH) == 0) { MIRT_STATS(tc1 = tc2 = clock64()); }
         // ---- classify; paths that end here without drawing (miss, emitter) are closed first
         HitInfo h;
         DevShade m;

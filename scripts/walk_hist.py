@@ -6,7 +6,7 @@ sys.path.insert(0, os.getcwd())
 import ray_tracing_amd as rt
 L = rt.lib()
 cut = int(os.environ.get("CUT", "0"))
-for scene, spp, depth, (W, H), kw in [("random", 8, 50, (1920, 1080), {}), ("final", 8, 50, (1920, 1080), {}),
+for scene, spp, depth, (W, H), kw in [("cornell", 64, 50, (1920, 1080), {}), ("random", 8, 50, (1920, 1080), {}), ("final", 8, 50, (1920, 1080), {}),
                                       ("random", 2, 10, (3840, 2160), {"random_num": 500})]:
     sc = rt.select_scene(scene, **kw)
     if cut and scene == "final":

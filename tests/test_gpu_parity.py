@@ -420,7 +420,8 @@ def test_ragged_frame_sizes(rt, oracle, earth, w, h):
 
 
 @pytest.mark.parametrize("name,spp,size", [("cornell", 24, (64, 36)), ("smoke", 8, (64, 36)), ("random", 8, (64, 36)),
-                                           ("final", 4, (64, 36)), ("2psp", 8, (37, 19)), ("random", 3, (130, 70))])
+                                           ("final", 4, (64, 36)), ("2psp", 8, (37, 19)), ("random", 3, (130, 70)),
+                                           ("cornell", 17, (40, 24)), ("random", 33, (24, 16))])   # ragged last chunk
 def test_pixel_queue_kernel_equals_fused_kernel(rt, oracle, earth, name, spp, size):
     """The persistent kernel hands (pixel, sample chunk) items to its lanes from a shared counter. Every sample
     is the same path as in the one-pixel-per-lane kernel (equal segment counts); a chunk's samples are added
