@@ -560,8 +560,8 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
 // keeps its place and goes on in the next iteration, instead of the whole wave waiting for it.
 // `steps` receives the number of steps taken (statistics builds read it; otherwise it folds away).
 template <uint32_t F>
-MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t* stack,
-                        uint32_t stride, uint32_t& steps) {
+MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t min_lanes,
+                        uint32_t* stack, uint32_t stride, uint32_t& steps) {
     steps = 0;
     for (;;) {
         if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w);
@@ -574,6 +574,9 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
                 walk_leaf<F>(s, t_min, w, stack, stride);
                 ++steps;
             }
+            // few lanes left walking: they stop here too and go on next iteration, together with the walks
+            // the other lanes will have started by then
+            if ((uint32_t)__popcll(__ballot(w.ref != kWalkIdle)) < min_lanes) budget = steps;
         }
         if (w.ref != kWalkIdle || w.next >= n) break;  // out of budget, or every hierarchy walked
     }

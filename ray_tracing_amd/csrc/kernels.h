@@ -16,6 +16,7 @@ struct RenderArgs {
     uint32_t* work_counter;             // pixel queue of the persistent kernel: zero before every launch
     uint32_t loop;                      // LOOP_*
     uint32_t walk_budget;               // hierarchy steps per lane and iteration of the persistent kernel
+    uint32_t walk_min_lanes;            // ... which also ends when fewer lanes than this are still walking
     // The persistent kernel's work items are (pixel, chunk of chunk_spp samples): n_chunks per pixel. With
     // more than one chunk the item sums go to partial[chunk * width * height + pixel] and are added to
     // accum in chunk order by a second kernel.

@@ -35,6 +35,7 @@ struct mirt_ctx {
     uint8_t* frame_dev = nullptr;
     size_t frame_dev_bytes = 0;
     uint32_t n_bvh_nodes = 0;                   // nodes of all hierarchies of the scene
+    uint32_t n_scan_records = 0;                // list-scan records of all list entries
     float4* partial = nullptr;                  // chunk sums of the persistent kernel (grown on demand)
     size_t partial_bytes = 0;
     unsigned long long* seg_counter = nullptr;  // kCounters device counters: segments, lane slots
@@ -530,6 +531,7 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     if ((rc = upload(c, insts, &s.instances))) return rc;
     if ((rc = upload(c, nodes, &s.bvh_nodes))) return rc;
     c->n_bvh_nodes = (uint32_t)nodes.size();
+    c->n_scan_records = (uint32_t)scan.size() - 1u;  // without the SC_END record
     if ((rc = upload(c, leaves, &s.bvh_leaves))) return rc;
     std::vector<uint32_t> bvh_entries;
     for (uint32_t e = 0; e < d->n_world; ++e)
@@ -708,6 +710,14 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
         // only repeats the list scan and shading code of the iteration (measured: `final` 1 440 Msamples/s
         // with 48 steps or unbounded, 1 340 with 24).
         a.walk_budget = budget ? budget : (c->n_bvh_nodes >= 65536u ? 24u : 48u);
+        // The walk phase of an iteration also ends when only a few lanes of the wave are still walking (they go
+        // on next iteration, together with the walks the other lanes start then): +10 % on `random` and on
+        // 1 M spheres, whose iterations are little more than the walk. Where an iteration carries long list
+        // scans, media or procedural / image textures, every extra iteration costs more than the idle lanes
+        // it saves (`final`: 1 430 -> 1 150 Msamples/s), so those scenes keep whole walks.
+        static const int lanes_env = [] { const char* e = std::getenv("MIRT_WALK_LANES"); return e ? std::atoi(e) : -1; }();
+        const bool heavy_iteration = (c->scene.features & (F_MEDIUM | F_TEX_NOISE | F_TEX_IMAGE)) != 0 || c->n_scan_records > 8u;
+        a.walk_min_lanes = lanes_env >= 0 ? (uint32_t)lanes_env : (heavy_iteration ? 0u : (c->n_bvh_nodes >= 65536u ? 32u : 16u));
     }
     // Long renders are cut into launches of at most kChunk samples per pixel: lanes of a wave
     // then finish within a few percent of each other and no launch runs for seconds.

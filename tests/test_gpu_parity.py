@@ -266,6 +266,8 @@ def test_error_paths(rt):
         ctx.render(1, 5)
     ctx.camera_set(rt.Camera.select_camera(1.0, "cornell"))
     ctx.render(1, 5)
+    with pytest.raises(rt.MirtError, match="kernel"):
+        ctx.render(1, 5, kernel=rt.KERNEL_QUEUE + 1)
     with pytest.raises(rt.MirtError, match="len"):
         ctx.resolve_rgba8(np.zeros(8 * 8 * 4 - 1, dtype=np.uint8))
     ctx.width = 9
