@@ -553,15 +553,20 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
     }
 }
 
-// A bounded piece of the same walk: at most `budget` node and leaf steps for this lane, continuing where
-// the lane's last call stopped (w.next hierarchies started, w.ref / stack as left). Returns true when
-// the walk is complete. A render loop that calls this once per iteration lets the lanes whose walk is
-// over shade and start their next segment while a lane with a long walk (a ray through a dense cluster)
-// keeps its place and goes on in the next iteration, instead of the whole wave waiting for it.
+// A bounded piece of the same walk, continuing where the lane's last call stopped (w.next hierarchies started,
+// w.ref / stack as left); returns true when the walk is complete. A render loop that calls this once per
+// iteration lets the lanes whose walk is over shade and start their next segment while a lane with a long
+// walk keeps its place and goes on in the next iteration, instead of the whole wave waiting for it. The walk
+// code is bound by instruction issue at a fifth of the lanes active, so three things end a turn early:
+//   budget      the lane has taken this many node / leaf steps;
+//   min_lanes   fewer lanes of the wave than this are still walking: they stop too, and continue together
+//               with the walks the other lanes will have started by the next iteration;
+//   node_lanes  fewer lanes than this are still descending through interior nodes: the descent pauses and the
+//               lanes that hold leaves intersect them now rather than after the last straggler.
 // `steps` receives the number of steps taken (statistics builds read it; otherwise it folds away).
 template <uint32_t F>
 MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t min_lanes,
-                        uint32_t* stack, uint32_t stride, uint32_t& steps) {
+                        uint32_t node_lanes, uint32_t* stack, uint32_t stride, uint32_t& steps) {
     steps = 0;
     for (;;) {
         if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w);
@@ -569,6 +574,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
             while (ref_is_node(w.ref) && steps < budget) {
                 walk_node(s, t_min, w, stack, stride);
                 ++steps;
+                if ((uint32_t)__popcll(__ballot(ref_is_node(w.ref))) < node_lanes) break;
             }
             if (ref_is_leaf(w.ref)) {
                 walk_leaf<F>(s, t_min, w, stack, stride);

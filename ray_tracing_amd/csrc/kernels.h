@@ -15,8 +15,11 @@ struct RenderArgs {
     unsigned long long* segment_counter;
     uint32_t* work_counter;             // pixel queue of the persistent kernel: zero before every launch
     uint32_t loop;                      // LOOP_*
-    uint32_t walk_budget;               // hierarchy steps per lane and iteration of the persistent kernel
-    uint32_t walk_min_lanes;            // ... which also ends when fewer lanes than this are still walking
+    // Hierarchy walks in the persistent kernel, per iteration: a lane takes at most walk_budget node / leaf steps;
+    // the walk phase ends for the whole wave when fewer than walk_min_lanes lanes are still walking; the descent
+    // through interior nodes pauses for a leaf round when fewer than walk_node_lanes lanes are still descending.
+    // A lane whose walk is not over continues in the next iteration.
+    uint32_t walk_budget, walk_min_lanes, walk_node_lanes;
     // The persistent kernel's work items are (pixel, chunk of chunk_spp samples): n_chunks per pixel. With
     // more than one chunk the item sums go to partial[chunk * width * height + pixel] and are added to
     // accum in chunk order by a second kernel.

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     bool walking = false;  // ... which is not over yet
     bool closed = false;   // the lane's path ended in its last scatter; no ray to trace this iteration
     uint32_t walk_n = 0;
-    const uint32_t walk_budget = a.walk_budget, walk_min_lanes = a.walk_min_lanes;
+    const uint32_t walk_budget = a.walk_budget, walk_min_lanes = a.walk_min_lanes, walk_node_lanes = a.walk_node_lanes;
     wk.ref = kWalkIdle;
     wk.next = wk.sp = 0;
 
@@ -391,7 +391,11 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
             }
             uint32_t wsteps = 0;
             MIRT_STATS(tc1 = clock64());
-            if (alive && !closed) walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, walk_min_lanes, stack, kBlock, wsteps);
+            // the lane thresholds are stated for a full wave: scale them to the lanes this wave still has
+            const uint32_t live = (uint32_t)__popcll(__ballot(alive));
+            if (alive && !closed)
+                walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, (walk_min_lanes * live) >> 6,
+                                         (walk_node_lanes * live) >> 6, stack, kBlock, wsteps);
             MIRT_STATS(tc2 = clock64());
             MIRT_STATS(walk_histogram(alive, wsteps));
             ready = alive && !walking;

@@ -700,24 +700,17 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     a.work_counter = reinterpret_cast<uint32_t*>(c->seg_counter + kCounters);
     a.loop = p->kernel == MIRT_KERNEL_FUSED ? LOOP_FUSED : (p->kernel == MIRT_KERNEL_QUEUE ? LOOP_QUEUE : LOOP_AUTO);
     {
-        static const uint32_t budget = [] {
-            const char* e = std::getenv("MIRT_WALK_BUDGET");
-            const long v = e ? std::atol(e) : 0;
-            return v > 0 ? (uint32_t)v : 0u;
-        }();
-        // Deep hierarchies have walks of very unequal length (1 M spheres: 33 steps on average, 93 for the
-        // longest lane of a wave) and gain 30 % from short turns; on small ones a turn that cuts walks short
-        // only repeats the list scan and shading code of the iteration (measured: `final` 1 440 Msamples/s
-        // with 48 steps or unbounded, 1 340 with 24).
-        a.walk_budget = budget ? budget : (c->n_bvh_nodes >= 65536u ? 24u : 48u);
-        // The walk phase of an iteration also ends when only a few lanes of the wave are still walking (they go
-        // on next iteration, together with the walks the other lanes start then): +10 % on `random` and on
-        // 1 M spheres, whose iterations are little more than the walk. Where an iteration carries long list
-        // scans, media or procedural / image textures, every extra iteration costs more than the idle lanes
-        // it saves (`final`: 1 430 -> 1 150 Msamples/s), so those scenes keep whole walks.
-        static const int lanes_env = [] { const char* e = std::getenv("MIRT_WALK_LANES"); return e ? std::atoi(e) : -1; }();
+        // How the persistent kernel shares a wave between its walks (kernels.h). Measured at 1080p with
+        // (lanes walking, lanes descending) out of 64: `random` 1 740 Msamples/s with whole walks, 2 300 with
+        // (24, 16); 1 M spheres at 4K 500 / 1 007; `final` 1 430 with whole walks, 1 285 with (24, 16), 1 610
+        // with (8, 8). Where an iteration carries long list scans, media or procedural / image textures
+        // (`final`), every extra iteration costs more, so walks are cut less.
+        auto env = [](const char* name) { const char* e = std::getenv(name); return e ? std::atol(e) : -1l; };
+        static const long budget_env = env("MIRT_WALK_BUDGET"), lanes_env = env("MIRT_WALK_LANES"), node_env = env("MIRT_NODE_LANES");
         const bool heavy_iteration = (c->scene.features & (F_MEDIUM | F_TEX_NOISE | F_TEX_IMAGE)) != 0 || c->n_scan_records > 8u;
-        a.walk_min_lanes = lanes_env >= 0 ? (uint32_t)lanes_env : (heavy_iteration ? 0u : (c->n_bvh_nodes >= 65536u ? 32u : 16u));
+        a.walk_budget = budget_env > 0 ? (uint32_t)budget_env : 48u;
+        a.walk_min_lanes = lanes_env >= 0 ? (uint32_t)lanes_env : (heavy_iteration ? 8u : 24u);
+        a.walk_node_lanes = node_env >= 0 ? (uint32_t)node_env : (heavy_iteration ? 8u : 16u);
     }
     // Long renders are cut into launches of at most kChunk samples per pixel: lanes of a wave
     // then finish within a few percent of each other and no launch runs for seconds.
