@@ -41,8 +41,9 @@ struct RayBatchArgs {
     float* color;       // ray_color, n x 3
 };
 
-// One thread per pixel walks all samples of the call: camera ray, then one ray segment per loop
-// iteration (trace + shade) with the path state in registers.
+// Renders a sample range into a.accum with the persistent kernel or its one-pixel-per-lane form (a.loop): camera
+// ray, then one ray segment per loop iteration (trace + shade) with the path state in registers. With
+// a.n_chunks > 1 the launch is followed by the pass that adds the chunk sums in a.partial to a.accum.
 hipError_t launch_render_fused(const RenderArgs& a, hipStream_t stream);
 hipError_t launch_first_hit(const RayBatchArgs& a, hipStream_t stream);
 hipError_t launch_ray_color(const RayBatchArgs& a, hipStream_t stream);

@@ -1,11 +1,14 @@
 // gfx950 kernels of the path-tracing backend.
 //
-//   render_fused_kernel  the per-pixel sample loop of Renderer::draw (renderer.rs:97-110): one
-//                        lane owns one pixel and walks its samples; each loop iteration is one ray
-//                        segment of ray_color (renderer.rs:197-237) — trace, shade, scatter — with
-//                        ray, throughput and RNG position in registers. A lane that finishes a
-//                        path starts its next sample in the same iteration, so the 64 lanes of a
-//                        wave stay busy although path lengths differ from 1 to max_depth.
+//   render_queue_kernel  the per-pixel sample loop of Renderer::draw (renderer.rs:97-110) as a persistent
+//                        kernel: lanes draw (pixel, chunk of samples) items from one counter; each loop
+//                        iteration is one ray segment of ray_color (renderer.rs:197-237) — trace, shade,
+//                        scatter — with ray, throughput and RNG position in registers. A lane that
+//                        finishes a path starts its next sample in the same iteration, one that finishes
+//                        its item takes the next, so the 64 lanes of a wave stay busy although path
+//                        lengths differ from 1 to max_depth and pixels differ in cost.
+//   reduce_chunks_kernel adds the chunk sums of every pixel, in chunk order, to the accumulation buffer.
+//   render_fused_kernel  the same loop with one lane = one pixel for the whole launch.
 //   first_hit_kernel     world.hit(ray, 0.001, inf) for explicit rays (deterministic check).
 //   ray_color_kernel     one un-sanitised radiance sample per explicit ray.
 //   resolve_kernel       mean, clamp, sqrt, *256 -> RGBA8 with the row flip (renderer.rs:97,109-116).
