@@ -107,7 +107,9 @@ def build(force=False):
 
 
 def lib():
-    """Load libmirt.so. Raises if the HIP library has not been built — there is no fallback."""
+    """Load libmirt.so. Raises if the HIP library has not been built — there is no fallback.
+    A process that also uses torch on the GPU has to import torch first: torch ships its own HIP runtime under the
+    same library name, and if the system's one is already loaded for libmirt torch finds no device."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):

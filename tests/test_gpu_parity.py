@@ -253,6 +253,28 @@ def test_full_size_properties(rt, oracle, earth):
     assert (frame[ly, lx, :3] == 255).all()
 
 
+def test_4k_frame_into_caller_owned_buffer(rt, oracle, earth):
+    """3840x2160 (the size of the multi-GPU configuration) rendered into a caller-owned device buffer, as the
+    multi-GPU split does before its reduce: the persistent kernel's chunk slots (16 x 8.3 M pixels) and the
+    one-pixel-per-lane kernel give the same image, the caller's tensor receives it, and the row sums show the
+    box where it should be (nothing left of it, the emitter at the top)."""
+    w, h, spp = 3840, 2160, 3
+    _, ctx, _ = make(rt, oracle, earth, "cornell", w, h)
+    owner = rt.Context(0)                   # stands for the caller: its frame buffer is device memory ctx does not own
+    owner.frame_begin(w, h)
+    ctx.frame_begin(w, h, owner.accum_device_ptr())
+    ctx.render(spp, 50, seed=4, kernel=rt.KERNEL_QUEUE)
+    ctx.synchronize()
+    got = owner.read_accum()
+    assert (ctx.read_accum() == got).all()
+    ctx.frame_begin(w, h)
+    ctx.render(spp, 50, seed=4, kernel=rt.KERNEL_FUSED)
+    want = ctx.read_accum()
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
+    assert (got[..., 3] == spp).all()
+    assert (got[:, :80, :3] == 0).all() and got[:, w // 2 - 100:w // 2 + 100, :3].sum() > 0
+
+
 def test_error_paths(rt):
     ctx = rt.Context(0)
     with pytest.raises(rt.MirtError, match="no scene"):
