@@ -232,9 +232,10 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(Rend
 // for the most expensive pixel of a tile or the most expensive tile of a launch: lanes idle only while the
 // last items of the whole launch finish. An item is rendered by exactly one lane, sample after sample.
 struct ItemQueue {
-    uint32_t pos;            // slots of the wave's current tile already handed out (64: none left)
-    uint32_t x0, y0, chunk;  // that tile's origin and sample chunk (all wave-uniform)
-    bool drained;            // the global counter has passed the last tile
+    // all wave-uniform, packed into two words because the list kernels have no scalar registers to spare:
+    uint32_t chunk_pos;  // sample chunk << 7 | slots of the wave's current tile already handed out (64: none left)
+    uint32_t origin;     // that tile's origin, x | y << 16
+    bool drained;        // the global counter has passed the last tile
 };
 
 // Hands an item to every lane with `need`: pixel position and chunk; false once the launch has none left.
@@ -249,7 +250,7 @@ __device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* co
     for (;;) {
         const unsigned long long m = __ballot(need && !got);
         if (m == 0) break;
-        if (q.pos == 64u) {
+        if ((q.chunk_pos & 127u) == 64u) {
             if (q.drained) break;
             uint32_t c = 0;
             if (lane == 0) c = atomicAdd(counter, 1u);
@@ -258,22 +259,21 @@ __device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* co
                 q.drained = true;
                 break;
             }
-            q.chunk = c / n_tiles;  // wave-uniform arithmetic, once per 64 items
-            const uint32_t tile = c - q.chunk * n_tiles, ty = tile / tiles_x;
-            q.y0 = ty * 8u;
-            q.x0 = (tile - ty * tiles_x) * 8u;
-            q.pos = 0;
+            const uint32_t ch = c / n_tiles;  // wave-uniform arithmetic, once per 64 items
+            const uint32_t tile = c - ch * n_tiles, ty = tile / tiles_x;
+            q.origin = ((tile - ty * tiles_x) * 8u) | (ty * 8u) << 16;
+            q.chunk_pos = ch << 7;
         }
-        const uint32_t avail = 64u - q.pos;
+        const uint32_t pos = q.chunk_pos & 127u, avail = 64u - pos;
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (need && !got && rank < avail) {
-            const uint32_t in = q.pos + rank;
-            x = q.x0 + (in & 7u);
-            y = q.y0 + (in >> 3);
-            chunk = q.chunk;
+            const uint32_t in = pos + rank;
+            x = (q.origin & 0xffffu) + (in & 7u);
+            y = (q.origin >> 16) + (in >> 3);
+            chunk = q.chunk_pos >> 7;
             got = true;
         }
-        q.pos += min((uint32_t)__popcll(m), avail);
+        q.chunk_pos += min((uint32_t)__popcll(m), avail);
     }
     return got;
 }
@@ -304,13 +304,15 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     const uint32_t tiles_x = (a.width + 7u) / 8u, tiles_y = (a.height + 7u) / 8u;
     const uint32_t n_tiles = tiles_x * tiles_y;
     const bool jitter = a.jitter != 0;
-    ItemQueue q{64u, 0u, 0u, 0u, false};
+    const uint32_t max_depth = a.max_depth;
+    ItemQueue q{64u, 0u, false};
 
     // the lane's work item (a pixel and a run of its samples) and its path
-    uint32_t pixel = 0, x = 0, y = 0, sample = a.spp_begin, sample_end = a.spp_begin, slot = 0;
+    // (position packed x | y << 16, chunk slot derived when the item is stored: the list variants run at 80 VGPRs)
+    uint32_t pixel = 0, xy = 0, sample = a.spp_begin, sample_end = a.spp_begin;
     V3 acc = v3(0.f, 0.f, 0.f);
     bool alive = false;
-    uint32_t depth_left = a.max_depth, bounce = 0;
+    uint32_t bounce = 0;  // scatters of the lane's path so far = draws' bounce index (renderer.rs:198: depth - 1 each)
     Ray ray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f), 0.f};
     V3 thr = v3(1.f, 1.f, 1.f);
     uint32_t segments = 0, rounds = 0;
@@ -333,17 +335,17 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     const uint32_t chunk_spp = a.chunk_spp, n_chunks = a.n_chunks, n_pixels = a.width * a.height;
     const float spp_count = (float)a.spp_count;
     float4* const partial = a.partial;
-    auto next_pixel = [&q, &alive, &x, &y, &pixel, &sample, &sample_end, &slot, &acc, work_counter, n_tiles, tiles_x, n_chunks, width,
-                       height, spp_begin, spp_last, chunk_spp, n_pixels](bool need) {
+    auto next_pixel = [&q, &alive, &xy, &pixel, &sample, &sample_end, &acc, work_counter, n_tiles, tiles_x, n_chunks, width, height,
+                       spp_begin, spp_last, chunk_spp](bool need) {
         for (;;) {
             if (__ballot(need) == 0) break;
-            uint32_t chunk = 0;
+            uint32_t chunk = 0, x = 0, y = 0;
             const bool got = take_items(need, q, work_counter, n_tiles, tiles_x, n_chunks, x, y, chunk);
             if (need) {
                 alive = got;
                 if (alive) {
                     pixel = y * width + x;
-                    slot = chunk * n_pixels + pixel;
+                    xy = x | y << 16;
                     sample = spp_begin + chunk * chunk_spp;
                     sample_end = min(sample + chunk_spp, spp_last);
                     acc = v3(0.f, 0.f, 0.f);
@@ -356,13 +358,14 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     // straight to the accumulation buffer; otherwise to the item's own slot, and reduce_chunks_kernel adds
     // the slots of a pixel in chunk order — no floating-point atomics, so the result does not depend on
     // which lane rendered what, or when.
-    auto flush_pixel = [&pixel, &slot, &acc, accum, partial, spp_count, n_chunks]() {
+    auto flush_pixel = [&pixel, &sample_end, &acc, accum, partial, spp_count, n_chunks, n_pixels, spp_begin, chunk_spp]() {
         if (n_chunks == 1u) {
             float4 v = accum[pixel];
             v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += spp_count;
             accum[pixel] = v;
         } else {
-            partial[slot] = make_float4(acc.x, acc.y, acc.z, 0.f);
+            const uint32_t chunk = (sample_end - 1u - spp_begin) / chunk_spp;
+            partial[chunk * n_pixels + pixel] = make_float4(acc.x, acc.y, acc.z, 0.f);
         }
     };
 
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     if (alive) {
         Rng g;
         g.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
-        ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, g);
+        ray = camera_ray<PINHOLE>(a.cam, xy & 0xffffu, xy >> 16, a.width, a.height, jitter, g);
     }
     while (__ballot(alive) != 0) {
         ++rounds;
@@ -454,20 +457,18 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
 
         if (ready && alive && !ended) {
             const bool cont = scatter<F>(a.scene, tb, m, h, g, ray, thr);
-            --depth_left;
             ++bounce;
             // absorbed, or renderer.rs:198-200: the next level returns 0. The sample is complete; its lane sits
             // out the trace of the next iteration and gets there what every path that ends gets: the item
             // check and a camera ray from that iteration's Philox block. (Doing both here instead means a
             // second Philox block and camera ray issued for the one or two lanes of a wave in this state.)
-            if (!cont || depth_left == 0) {
+            if (!cont || bounce == max_depth) {
                 ++sample;
                 closed = true;
             }
         } else if (ready && alive) {
-            ray = camera_ray<PINHOLE>(a.cam, x, y, a.width, a.height, jitter, g);
+            ray = camera_ray<PINHOLE>(a.cam, xy & 0xffffu, xy >> 16, a.width, a.height, jitter, g);
             thr = v3(1.f, 1.f, 1.f);
-            depth_left = a.max_depth;
             bounce = 0;
         }
         MIRT_STATS(const long long tc3 = clock64(); ph0 += tc1 - tc0; ph1 += tc2 - tc1; ph2 += tc3 - tc2);
