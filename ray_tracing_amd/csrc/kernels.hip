@@ -315,7 +315,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     uint32_t bounce = 0;  // scatters of the lane's path so far = draws' bounce index (renderer.rs:198: depth - 1 each)
     Ray ray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f), 0.f};
     V3 thr = v3(1.f, 1.f, 1.f);
-    uint32_t segments = 0, rounds = 0;
+    uint32_t segments = 0, rounds = 0;  // of the whole wave (scalar registers)
     MIRT_STATS(const long long t_birth = clock64(); long long ph0 = 0, ph1 = 0, ph2 = 0);
     Walk wk;               // the lane's walk of the hierarchies, kept from iteration to iteration
     bool walking = false;  // ... which is not over yet
@@ -393,8 +393,8 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 wk.next = 0;
                 wk.ref = kWalkIdle;
                 walk_n = walk_count(a.scene, ray);
-                ++segments;
             }
+            segments += (uint32_t)__popcll(__ballot(alive && !walking && !closed));
             uint32_t wsteps = 0;
             MIRT_STATS(tc1 = clock64());
             // the lane thresholds are stated for a full wave: scale them to the lanes this wave still has
@@ -410,8 +410,8 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         } else if (alive && !closed) {
             DrawKey key{pixel, sample, bounce, a.seed};
             world_hit<FT>(a.scene, ray, key, stack, kBlock, t, prim);
-            ++segments;
         }
+        if constexpr ((FT & F_BVH) == 0) segments += (uint32_t)__popcll(__ballot(alive && !closed));
         if constexpr ((FT & F_BVH) == 0) { MIRT_STATS(tc1 = tc2 = clock64()); }
         // ---- classify; paths that end here without drawing (miss, emitter) are closed first
         HitInfo h;
@@ -474,7 +474,6 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         MIRT_STATS(const long long tc3 = clock64(); ph0 += tc1 - tc0; ph1 += tc2 - tc1; ph2 += tc3 - tc2);
     }
     MIRT_STATS(wave_totals(clock64() - t_birth, ph0, ph1, ph2, rounds));
-    for (int off = 32; off > 0; off >>= 1) segments += __shfl_down(segments, off);
     if ((threadIdx.x & 63u) == 0 && a.segment_counter) {
         atomicAdd(a.segment_counter, (unsigned long long)segments);
         atomicAdd(a.segment_counter + 1, 64ull * rounds);
