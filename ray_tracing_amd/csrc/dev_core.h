@@ -689,10 +689,13 @@ MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim)
 // ---------------------------------------------------------------------------------------------
 // textures (texture.rs, perlin.rs)
 // ---------------------------------------------------------------------------------------------
-// perlin.rs:24-63
+// perlin.rs:24-63. The reference's corner weight  i*u + (1-i)*(1-u)  and offset  u - i  are written out for
+// i = 0 and i = 1 (1 - u, u and u, u - 1): the same values bit for bit (0*x + y and 1*x are exact for finite
+// x), without the multiplications by constants 0 and 1 that IEEE semantics forbid the compiler to drop, and
+// with the product of the first two weights shared by the two corners that differ in the third index only.
 MIRT_DEV float perlin_noise(const DevPerlin& pl, V3 p) {
-    float fl[3] = {floorf(p.x), floorf(p.y), floorf(p.z)};
-    int idx[3] = {(int)fl[0], (int)fl[1], (int)fl[2]};
+    const float fl[3] = {floorf(p.x), floorf(p.y), floorf(p.z)};
+    const int ix = (int)fl[0], iy = (int)fl[1], iz = (int)fl[2];
     float uvw[3];
     const float pc[3] = {p.x, p.y, p.z};
 #pragma unroll
@@ -700,22 +703,24 @@ MIRT_DEV float perlin_noise(const DevPerlin& pl, V3 p) {
         float x = pc[a] - fl[a];
         uvw[a] = x * x * (3.f - 2.f * x);
     }
+    const float wu[2] = {1.f - uvw[0], uvw[0]}, wv[2] = {1.f - uvw[1], uvw[1]}, ww[2] = {1.f - uvw[2], uvw[2]};
+    const float du[2] = {uvw[0], uvw[0] - 1.f}, dv[2] = {uvw[1], uvw[1] - 1.f}, dw[2] = {uvw[2], uvw[2] - 1.f};
+    const int px[2] = {pl.perm[0][ix & 0xff], pl.perm[0][(ix + 1) & 0xff]};
+    const int py[2] = {pl.perm[1][iy & 0xff], pl.perm[1][(iy + 1) & 0xff]};
+    const int pz[2] = {pl.perm[2][iz & 0xff], pl.perm[2][(iz + 1) & 0xff]};
     float accm = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            const float puv = wu[i] * wv[j];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                int ind = pl.perm[0][(idx[0] + i) & 0xff] ^ pl.perm[1][(idx[1] + j) & 0xff] ^ pl.perm[2][(idx[2] + k) & 0xff];
-                V3 c = v3(pl.grad[ind][0], pl.grad[ind][1], pl.grad[ind][2]);
-                V3 weight = v3(uvw[0] - (float)i, uvw[1] - (float)j, uvw[2] - (float)k);
-                float prod = 1.f;
-                prod = prod * ((float)i * uvw[0] + (1.f - (float)i) * (1.f - uvw[0]));
-                prod = prod * ((float)j * uvw[1] + (1.f - (float)j) * (1.f - uvw[1]));
-                prod = prod * ((float)k * uvw[2] + (1.f - (float)k) * (1.f - uvw[2]));
-                accm += dot(c, weight) * prod;
+                const int ind = px[i] ^ py[j] ^ pz[k];
+                const float4 c = *reinterpret_cast<const float4*>(pl.grad[ind]);
+                accm += ((c.x * du[i] + c.y * dv[j]) + c.z * dw[k]) * (puv * ww[k]);
             }
+        }
     return accm;
 }
 // perlin.rs:65-71
