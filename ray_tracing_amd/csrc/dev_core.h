@@ -77,6 +77,9 @@ MIRT_DEV void sincos_2pi(float u, float& sn, float& cs) {
     sn = __builtin_amdgcn_sinf(u);
     cs = __builtin_amdgcn_cosf(u);
 }
+// sin(x) from v_sin_f32 (argument in revolutions, reduced to one turn first): absolute error about 1e-6 up to
+// |x| of a few hundred — for texture patterns, where the reference's sin() only shapes a colour
+MIRT_DEV float fast_sin(float x) { return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189535f)); }
 // n / d from r = v_rcp(d) and one Newton step; NaN when d == 0 (callers reject NaN)
 MIRT_DEV float div_nr(float n, float d, float r) {
     float q = n * r;
@@ -742,14 +745,14 @@ MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 
     if ((F & F_TEX_CHECKER) && kind == TK_CHECKER) {
         // texture.rs:42-46
         float sines = 1.0f;
-        sines = sines * sinf(10.f * p.x);
-        sines = sines * sinf(10.f * p.y);
-        sines = sines * sinf(10.f * p.z);
+        sines = sines * fast_sin(10.f * p.x);
+        sines = sines * fast_sin(10.f * p.y);
+        sines = sines * fast_sin(10.f * p.z);
         return sines < 0.f ? v3(t.c1) : v3(t.c0);
     }
     if ((F & F_TEX_NOISE) && kind == TK_NOISE) {
         // texture.rs:64-68
-        float g = 0.5f * (1.f + sinf(t.c1[3] * p.z + 10.f * perlin_turb(s.perlins[t.perlin], p)));
+        float g = 0.5f * (1.f + fast_sin(t.c1[3] * p.z + 10.f * perlin_turb(s.perlins[t.perlin], p)));
         return v3(g, g, g);
     }
     if ((F & F_TEX_IMAGE) && kind == TK_IMAGE) {
