@@ -633,7 +633,9 @@ struct HitInfo {
 };
 
 template <uint32_t F>
-MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim) {
+// `need_uv`: the surface's texture reads u, v (only image textures do); the record keeps 0, 0 otherwise, so the
+// many hits that never look at them do not pay for acos / atan2.
+MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim, bool need_uv = true) {
     const DevPrim& p = tb.prims[prim];
     HitInfo h;
     h.u = 0.f;
@@ -655,7 +657,7 @@ MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim)
     if ((F & F_SPHERE) && (!(F & F_RECT) || kind == PK_SPHERE)) {
         // geo.rs:108-111
         V3 outward = (pl - sphere_center<F>(p, lr.time)) * fast_rcp(p.a[3]);
-        if (F & F_TEX_IMAGE) {
+        if ((F & F_TEX_IMAGE) && need_uv) {
             float theta = acosf(-outward.y);                    // geo.rs:71-75
             float phi = atan2f(-outward.z, outward.x) + kPi;
             h.u = phi / (2.f * kPi);
@@ -668,7 +670,7 @@ MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim)
         // geo.rs:205-211
         uint32_t xi, yi, zi;
         axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
-        if (F & F_TEX_IMAGE) {
+        if ((F & F_TEX_IMAGE) && need_uv) {
             h.u = (comp(pl, xi) - p.a[1]) / (p.a[2] - p.a[1]);
             h.v = (comp(pl, yi) - p.a[3]) / (p.b[0] - p.a[3]);
         }

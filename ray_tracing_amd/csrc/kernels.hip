@@ -109,7 +109,7 @@ __device__ __forceinline__ void shade_segment(const RenderArgs& a, const Tables&
         ended = true;
     } else {
         m = tb.shade[prim];
-        h = finalize_hit<F>(tb, ray, t, prim);
+        h = finalize_hit<F>(tb, ray, t, prim, m.tex_kind == TK_IMAGE);
         if ((F & F_MAT_LIGHT) && m.mat_kind == MK_DIFFUSE_LIGHT) {
             e = cmul(thr, emitted_radiance<F>(a.scene, m, h));
             ended = true;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 ended = true;
             } else {
                 m = tb.shade[prim];
-                h = finalize_hit<F>(tb, ray, t, prim);
+                h = finalize_hit<F>(tb, ray, t, prim, m.tex_kind == TK_IMAGE);
                 if ((F & F_MAT_LIGHT) && m.mat_kind == MK_DIFFUSE_LIGHT) {
                     e = cmul(thr, emitted_radiance<F>(a.scene, m, h));
                     ended = true;
