@@ -13,7 +13,7 @@ struct RenderArgs {
     uint32_t max_depth, seed, jitter;
     float4* accum;                      // width*height, pixel y*width + x, y = 0 at the bottom
     unsigned long long* segment_counter;
-    uint32_t* work_counter;             // pixel queue of the persistent kernel: zero before every launch
+    uint32_t* work_counter;             // item counters of the persistent kernel (kWorkCounterBytes): zero before every launch
     uint32_t loop;                      // LOOP_*
     // Hierarchy walks in the persistent kernel, per iteration: a lane takes at most walk_budget node / leaf steps;
     // the walk phase ends for the whole wave when fewer than walk_min_lanes lanes are still walking; the descent
@@ -27,6 +27,7 @@ struct RenderArgs {
     float4* partial;
 };
 enum : uint32_t { LOOP_AUTO = 0, LOOP_FUSED = 1, LOOP_QUEUE = 2 };
+constexpr size_t kWorkCounterBytes = 8 * 128;  // eight counters, one per 128-byte line
 // Whether launch_render_fused() renders these arguments with the persistent pixel-queue kernel.
 bool render_uses_queue(const RenderArgs& a);
 

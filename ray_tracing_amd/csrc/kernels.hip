@@ -232,18 +232,22 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(Rend
 // for the most expensive pixel of a tile or the most expensive tile of a launch: lanes idle only while the
 // last items of the whole launch finish. An item is rendered by exactly one lane, sample after sample.
 struct ItemQueue {
-    // all wave-uniform, packed into two words because the list kernels have no scalar registers to spare:
+    // all wave-uniform, packed because the list kernels have no scalar registers to spare:
     uint32_t chunk_pos;  // sample chunk << 7 | slots of the wave's current tile already handed out (64: none left)
     uint32_t origin;     // that tile's origin, x | y << 16
-    bool drained;        // the global counter has passed the last tile
+    uint32_t dead;       // bit i: counter i has passed its last tile (all kItemCounters bits: the launch has no work left)
 };
+// The tiles are dealt to kItemCounters counters (tile run r belongs to counter r mod 8, which hands out r / 8), each
+// in its own 128-byte line. A wave draws from the counter of its workgroup (blockIdx mod 8) and moves on to the
+// others when that one is exhausted. One counter for the whole device costs nothing while items are long, but
+// with almost free samples (one sphere: 0.5 M trips in 6 ms) every trip queues behind all the others'.
+constexpr uint32_t kItemCounters = 8, kItemCounterStride = 32;  // stride in 32-bit words
 
 // Hands an item to every lane with `need`: pixel position and chunk; false once the launch has none left.
-// One trip to the counter fetches one wave-load. Longer runs (fixed, or a share of what is left) were measured:
-// they only pay on scenes with almost free samples (one sphere: 21 -> 48 Gsamples/s at 256 items), and cost
-// 3-50 % elsewhere, because neighbouring items cost alike and a wave that holds a long run of expensive ones
-// becomes the tail of the launch.
-__device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* counter, uint32_t n_tiles, uint32_t tiles_x,
+// One trip to a counter fetches one wave-load. Longer runs (fixed, or a share of what is left) were measured:
+// they only pay on scenes with almost free samples, and cost 3-50 % elsewhere, because neighbouring items cost
+// alike and a wave that holds a long run of expensive ones becomes the tail of the launch.
+__device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* counters, uint32_t n_tiles, uint32_t tiles_x,
                                            uint32_t n_chunks, uint32_t& x, uint32_t& y, uint32_t& chunk) {
     const uint32_t lane = threadIdx.x & 63u;
     bool got = false;
@@ -251,16 +255,20 @@ __device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* co
         const unsigned long long m = __ballot(need && !got);
         if (m == 0) break;
         if ((q.chunk_pos & 127u) == 64u) {
-            if (q.drained) break;
-            uint32_t c = 0;
-            if (lane == 0) c = atomicAdd(counter, 1u);
-            c = __builtin_amdgcn_readfirstlane(c);
-            if (c >= n_tiles * n_chunks) {
-                q.drained = true;
-                break;
+            uint32_t run = 0xffffffffu;
+            for (uint32_t a = 0; a < kItemCounters && run == 0xffffffffu; ++a) {
+                const uint32_t qi = (blockIdx.x + a) & (kItemCounters - 1u);
+                if (q.dead & (1u << qi)) continue;
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(counters + qi * kItemCounterStride, 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                const uint32_t r = c * kItemCounters + qi;
+                if (c < 0x1fffffffu && r < n_tiles * n_chunks) run = r;
+                else q.dead |= 1u << qi;
             }
-            const uint32_t ch = c / n_tiles;  // wave-uniform arithmetic, once per 64 items
-            const uint32_t tile = c - ch * n_tiles, ty = tile / tiles_x;
+            if (run == 0xffffffffu) break;  // every counter is exhausted
+            const uint32_t ch = run / n_tiles;  // wave-uniform arithmetic, once per 64 items
+            const uint32_t tile = run - ch * n_tiles, ty = tile / tiles_x;
             q.origin = ((tile - ty * tiles_x) * 8u) | (ty * 8u) << 16;
             q.chunk_pos = ch << 7;
         }
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     const uint32_t n_tiles = tiles_x * tiles_y;
     const bool jitter = a.jitter != 0;
     const uint32_t max_depth = a.max_depth;
-    ItemQueue q{64u, 0u, false};
+    ItemQueue q{64u, 0u, 0u};
 
     // the lane's work item (a pixel and a run of its samples) and its path
     // (position packed x | y << 16, chunk slot derived when the item is stored: the list variants run at 80 VGPRs)

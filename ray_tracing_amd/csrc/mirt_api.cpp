@@ -171,9 +171,9 @@ int mirt_create(int device, mirt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
-    // kCounters statistics words, then the pixel queue of the persistent render kernel
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), (kCounters + 1) * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(c->seg_counter, 0, (kCounters + 1) * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+    // kCounters statistics words, then (from byte 128) the item counters of the persistent render kernel
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), kCounters * sizeof(unsigned long long) + 128 + kWorkCounterBytes)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->seg_counter, 0, kCounters * sizeof(unsigned long long) + 128 + kWorkCounterBytes)) != hipSuccess) return bail("hipMemset", e);
     *out = c;
     return MIRT_OK;
 }
@@ -697,7 +697,7 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     a.max_depth = p->max_depth; a.seed = p->seed; a.jitter = p->jitter;
     a.accum = c->accum;
     a.segment_counter = c->seg_counter;
-    a.work_counter = reinterpret_cast<uint32_t*>(c->seg_counter + kCounters);
+    a.work_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->seg_counter) + 128);  // own lines, after the statistics words
     a.loop = p->kernel == MIRT_KERNEL_FUSED ? LOOP_FUSED : (p->kernel == MIRT_KERNEL_QUEUE ? LOOP_QUEUE : LOOP_AUTO);
     {
         // How the persistent kernel shares a wave between its walks (kernels.h). Measured at 1080p with
@@ -748,7 +748,7 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
             }
         }
         a.partial = c->partial;
-        HIP_TRY(c, hipMemsetAsync(a.work_counter, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(a.work_counter, 0, kWorkCounterBytes, c->stream));
         HIP_TRY(c, launch_render_fused(a, c->stream));
         ++launches;
     }
