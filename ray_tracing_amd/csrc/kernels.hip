@@ -226,8 +226,8 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(Rend
 }
 
 // The sample loop as a persistent kernel. The grid is only as large as the device holds at once. The work
-// items are (pixel, chunk of its samples); one global counter hands them out a wave-load at a time — counter
-// value c stands for the 64 pixel slots of 8x8 tile (c mod tiles) in sample chunk (c / tiles) — and a lane
+// items are (pixel, chunk of its samples); global counters hand them out a wave-load at a time — tile run
+// c stands for the 64 pixel slots of 8x8 tile (c mod tiles) in sample chunk (c / tiles) — and a lane
 // that has finished its item stores the sums and takes the next slot in the same iteration. Nothing waits
 // for the most expensive pixel of a tile or the most expensive tile of a launch: lanes idle only while the
 // last items of the whole launch finish. An item is rendered by exactly one lane, sample after sample.
