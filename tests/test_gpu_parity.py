@@ -479,6 +479,31 @@ def test_pixel_queue_kernel_equals_fused_kernel(rt, oracle, earth, name, spp, si
     assert (one[rt.KERNEL_QUEUE] == one[rt.KERNEL_FUSED]).all()
 
 
+@pytest.mark.parametrize("budget,lanes,node_lanes", [(1, 0, 0), (2, 64, 64), (3, 63, 1), (1000, 1, 63)])
+def test_walks_resume_correctly_whatever_cuts_them(budget, lanes, node_lanes):
+    """The persistent kernel cuts hierarchy walks into turns (a step budget, a minimum of lanes still walking, a
+    minimum of lanes still descending) and resumes them in later iterations. The limits only change when a walk
+    pauses, never what it finds: with extreme settings (a turn of one step; every round cut; never cut) the images
+    of the hierarchy scenes still equal the one-pixel-per-lane kernel's, which walks without pausing. The limits
+    are read from the environment once per process, hence the child process."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, ray_tracing_amd as rt\n"
+        "for name, spp in (('random', 6), ('final', 3)):\n"
+        "    sc = rt.select_scene(name); ctx = rt.Context(0); ctx.scene_upload(sc)\n"
+        "    ctx.camera_set(rt.Camera.select_camera(64 / 36, name))\n"
+        "    out = []\n"
+        "    for k in (rt.KERNEL_FUSED, rt.KERNEL_QUEUE):\n"
+        "        ctx.frame_begin(64, 36); ctx.render(spp, 50, seed=9, kernel=k); out.append((ctx.read_accum(), ctx.stats()['segments']))\n"
+        "    np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-6, atol=1e-6)\n"
+        "    assert out[1][1] == out[0][1]\n"
+        "print('ok')\n")
+    env = dict(os.environ, MIRT_WALK_BUDGET=str(budget), MIRT_WALK_LANES=str(lanes), MIRT_NODE_LANES=str(node_lanes))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
 def _sphere_scene(rt, centres, radius, entry_kind):
     """A hand-made descriptor: spheres with one Lambertian material in a single world entry of the given kind."""
     C = rt.C
