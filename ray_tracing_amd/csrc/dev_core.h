@@ -9,7 +9,8 @@
 // transforms, plane / sphere roots, extent tests) is evaluated with separately rounded IEEE
 // operations in the reference's order, so first-hit ids agree exactly with a CPU evaluation; the
 // one liberty is that the plane division uses a shared reciprocal plus one Newton step (result
-// correctly rounded except with probability ~2^-21). Shading (sampling directions, pdfs,
+// correctly rounded except with probability ~2^-21), and the free path drawn inside a constant medium takes
+// its logarithm from v_log_f32 (the draw is random; t stays within 1e-6). Shading (sampling directions, pdfs,
 // throughput) uses the hardware approximations v_rcp / v_rsq / v_sqrt / v_sin / v_cos, which
 // perturb a sample by ~1e-6 relative and leave the estimator's expectation unchanged.
 #pragma once
@@ -400,7 +401,8 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
     float distance_inside_boundary = t2 - t1;
     uint32_t w0, w1, w2, w3;
     philox4x32_10(key.pixel, key.sample, 0u, key.bounce, STREAM_MEDIUM + __float_as_uint(p.a[3]), key.seed, w0, w1, w2, w3);
-    float hit_distance = p.a[2] * logf(unit_f32(w0));
+    // ln from the hardware log2 (1 ulp): the free path is a random draw, its last bit decides nothing
+    float hit_distance = p.a[2] * (__builtin_amdgcn_logf(unit_f32(w0)) * 0.6931471805599453f);
     if (hit_distance > distance_inside_boundary) return false;
     t_out = t1 + hit_distance;
     return true;
