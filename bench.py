@@ -30,7 +30,7 @@ UNPACKED_FP32_TFLOPS = 111.8
 # (profiles/r1/cornell_1080p_1024spp_v4_hbm_traffic_pmc.txt): 2 x FETCH_SIZE (gfx950 counts half of a wide read)
 # + WRITE_SIZE, in KiB. The persistent kernel writes one float4 per pixel and sample chunk (16 chunks x 33.2 MB)
 # and reads next to nothing; the pass that adds the chunks (reduce_chunks_kernel, 0.1 ms) reads them back once.
-MEASURED_TRAFFIC_BYTES = {("cornell", 1920, 1080, 1024): (2 * 6245.375 + 542527.9375) * 1024}
+MEASURED_TRAFFIC_BYTES = {("cornell", 1920, 1080, 1024): (2 * 6922.375 + 544951.65625) * 1024}
 
 def cpu_baseline(scene, width, height, depth, target_seconds=12.0):
     """The oracle (CPU restatement of the reference renderer) on this host's cores, on a bounded sample of
