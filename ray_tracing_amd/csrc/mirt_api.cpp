@@ -460,12 +460,12 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
             bool cuboids = q.prims_per_object == 6;
             for (uint32_t j = 0; cuboids && j < objs.size(); ++j) cuboids = is_cuboid(d->prims + objs[j].first_prim);
             const uint32_t records_per_object = cuboids ? 1u : q.prims_per_object;
-            // one object per leaf: measured against 2 / 3 / 4 / 6 spheres per leaf — 1 765 / 1 648 / 1 548 / 1 447 /
-            // 1 271 Msamples/s on `random`, 705 / 653 / 608 / 563 / 506 on 1 M spheres (a leaf test costs a step
-            // whether or not the ray comes near the second sphere; the box test that replaces it is cheaper)
-            const uint32_t leaf_objects = 1u;
-            if (leaf_objects * records_per_object > 16u) return bad("entry " + std::to_string(e) + ": prims_per_object is limited to 16");
-            BvhBuilder builder(nodes, slots, 32, leaf_objects, records_per_object);
+            // One object per leaf (the builder's rule): measured against 2 / 3 / 4 / 6 spheres per leaf — 1 765 /
+            // 1 648 / 1 548 / 1 447 / 1 271 Msamples/s on `random`, 705 / 653 / 608 / 563 / 506 on 1 M spheres (a
+            // leaf test costs a step whether or not the ray comes near the second sphere; the box test that
+            // replaces it is cheaper).
+            if (records_per_object > 16u) return bad("entry " + std::to_string(e) + ": prims_per_object is limited to 16");
+            BvhBuilder builder(nodes, slots, 32, records_per_object);
             q.bvh_root = builder.build(objs);
             slot_is_cuboid.resize(slots.size(), cuboids ? 1 : 0);  // marks the slots this entry added
             // the hit record of a BVH member is rebuilt with the entry's transform
