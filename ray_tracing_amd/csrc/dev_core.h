@@ -413,7 +413,7 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
 // leaves as runs of 32-byte primitive records, per-lane traversal stack in LDS.
 //
 // Traversal is written as a resumable walk: `Walk` holds everything a lane needs to continue
-// (local ray, current reference, stack depth, hierarchies started, closest hit so far), walk_node()
+// (current reference, stack depth, hierarchies started, closest hit so far), walk_node()
 // consumes one interior reference and walk_leaf() one leaf reference; walk_run() loops until the
 // walk is idle. (Interleaving the walk steps of a wave's lanes with shading rounds, so that lanes
 // whose walk ended early need not wait for the longest one, was measured and lost 5-20 %: a shading
@@ -428,13 +428,21 @@ MIRT_DEV bool ref_is_leaf(uint32_t ref) { return ref != kWalkIdle && (ref & kRef
 MIRT_DEV bool ref_is_node(uint32_t ref) { return !(ref & kRefLeaf); }
 
 struct Walk {
-    LRay lr;         // the ray in the frame of the hierarchy being walked
     uint32_t ref;    // current reference (interior node index or leaf run) or kWalkIdle
     uint32_t sp;     // entries on this lane's stack
     uint32_t next;   // how many of the scene's hierarchies this ray has started
     float closest;   // t of the closest hit so far (starts at the list scans' result)
     int best;        // its primitive, -1 = none
 };
+// The ray in the frame of hierarchy number k (world order). It is derived from the path's ray whenever a walk
+// starts or resumes instead of being carried in `Walk`: a walk that pauses over the shading code of an
+// iteration then holds five registers, not fifteen.
+template <uint32_t F>
+MIRT_DEV LRay walk_ray(const DevScene& s, const Ray& r, uint32_t k) {
+    const DevEntry& en = s.entries[s.bvh_entries[k]];
+    // 1-ulp reciprocals; walk_node() widens the far bound by more than that
+    return make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
+}
 
 // Number of hierarchies the ray has to walk. A ray with a NaN component hits no primitive (see
 // sphere_hit_c) but would pass every box test (min / max drop NaN operands) and visit whole trees: it
@@ -446,11 +454,10 @@ MIRT_DEV uint32_t walk_count(const DevScene& s, const Ray& r) {
 
 // Start the walk of the scene's hierarchy number w.next (world order) and count it as started.
 template <uint32_t F>
-MIRT_DEV void walk_begin(const DevScene& s, const Ray& r, Walk& w) {
-    const DevEntry& en = s.entries[s.bvh_entries[w.next++]];
-    // 1-ulp reciprocals; slab() widens the far bound by more than that
-    w.lr = make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
-    w.ref = en.bvh_root;
+MIRT_DEV void walk_begin(const DevScene& s, const Ray& r, Walk& w, LRay& lr) {
+    const uint32_t k = w.next++;
+    lr = walk_ray<F>(s, r, k);
+    w.ref = s.entries[s.bvh_entries[k]].bvh_root;
     w.sp = 0;
 }
 
@@ -465,12 +472,12 @@ MIRT_DEV void walk_pop(Walk& w, const uint32_t* stack, uint32_t stride) {
 // reciprocals), continue with the nearer hit child and push the other. The twelve plane distances are
 // six packed subtract / multiply pairs. `stack` is this lane's column of an LDS array laid out
 // [level][lane] (stride = blockDim.x words): pushes and pops are conflict-free.
-MIRT_DEV void walk_node(const DevScene& s, float t_min, Walk& w, uint32_t* stack, uint32_t stride) {
+MIRT_DEV void walk_node(const DevScene& s, float t_min, const LRay& lr, Walk& w, uint32_t* stack, uint32_t stride) {
     const float4* q = reinterpret_cast<const float4*>(s.bvh_nodes + w.ref);
     const float4 a = q[0], b = q[1], c = q[2];
     const uint4 refs = reinterpret_cast<const uint4*>(q)[3];
-    const f32x2 oxy = {w.lr.r.o.x, w.lr.r.o.y}, ozz = {w.lr.r.o.z, w.lr.r.o.z};
-    const f32x2 rxy = {w.lr.rinv.x, w.lr.rinv.y}, rzz = {w.lr.rinv.z, w.lr.rinv.z};
+    const f32x2 oxy = {lr.r.o.x, lr.r.o.y}, ozz = {lr.r.o.z, lr.r.o.z};
+    const f32x2 rxy = {lr.rinv.x, lr.rinv.y}, rzz = {lr.rinv.z, lr.rinv.z};
     const f32x2 l0 = (f32x2{a.x, a.y} - oxy) * rxy, h0 = (f32x2{a.z, a.w} - oxy) * rxy;
     const f32x2 l1 = (f32x2{b.x, b.y} - oxy) * rxy, h1 = (f32x2{b.z, b.w} - oxy) * rxy;
     const f32x2 z0 = (f32x2{c.x, c.y} - ozz) * rzz, z1 = (f32x2{c.z, c.w} - ozz) * rzz;
@@ -518,7 +525,7 @@ MIRT_DEV bool leaf_rec_hit(const DevScene& s, const DevLeafRec& rec, const LRay&
 
 // The records of one leaf, in object order (a later record wins a tie, as in ray.rs:123-133).
 template <uint32_t F>
-MIRT_DEV void walk_leaf(const DevScene& s, float t_min, Walk& w, const uint32_t* stack, uint32_t stride) {
+MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w, const uint32_t* stack, uint32_t stride) {
     const uint32_t first = w.ref & kRefLeafIndexMask, n = ((w.ref >> 27) & 15u) + 1u;
     for (uint32_t j = 0; j < n; ++j) {
         const DevLeafRec& rec = s.bvh_leaves[first + j];
@@ -526,13 +533,13 @@ MIRT_DEV void walk_leaf(const DevScene& s, float t_min, Walk& w, const uint32_t*
             // Cuboid (geo.rs:245-289): its six rects in list order — XY at z lo / hi, XZ at y lo / hi, YZ at
             // x lo / hi — from the two corners f = (lo.xyz, hi.xyz); ids prim .. prim + 5
             const float lx = rec.f[0], ly = rec.f[1], lz = rec.f[2], hx = rec.f[3], hy = rec.f[4], hz = rec.f[5];
-            face_pair_hit<0, 1, 2>(lz, hz, lx, hx, ly, hy, rec.prim, w.lr.r.o, w.lr.r.d, w.lr.rinv, t_min, w.closest, w.best);
-            face_pair_hit<0, 2, 1>(ly, hy, lx, hx, lz, hz, rec.prim + 2u, w.lr.r.o, w.lr.r.d, w.lr.rinv, t_min, w.closest, w.best);
-            face_pair_hit<1, 2, 0>(lx, hx, ly, hy, lz, hz, rec.prim + 4u, w.lr.r.o, w.lr.r.d, w.lr.rinv, t_min, w.closest, w.best);
+            face_pair_hit<0, 1, 2>(lz, hz, lx, hx, ly, hy, rec.prim, lr.r.o, lr.r.d, lr.rinv, t_min, w.closest, w.best);
+            face_pair_hit<0, 2, 1>(ly, hy, lx, hx, lz, hz, rec.prim + 2u, lr.r.o, lr.r.d, lr.rinv, t_min, w.closest, w.best);
+            face_pair_hit<1, 2, 0>(lx, hx, ly, hy, lz, hz, rec.prim + 4u, lr.r.o, lr.r.d, lr.rinv, t_min, w.closest, w.best);
             continue;
         }
         float t;
-        if (leaf_rec_hit<F>(s, rec, w.lr, t_min, w.closest, t)) {
+        if (leaf_rec_hit<F>(s, rec, lr, t_min, w.closest, t)) {
             w.closest = t;
             w.best = (int)rec.prim;
         }
@@ -546,14 +553,15 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
     const uint32_t n = walk_count(s, r);
     w.next = 0;
     w.ref = kWalkIdle;
+    LRay lr;
     while (w.next < n) {
-        walk_begin<F>(s, r, w);
+        walk_begin<F>(s, r, w, lr);
         // Two nested loops rather than one step of either kind per iteration: the lanes of a wave
         // descend through interior nodes until each of them holds a leaf (or is done), then all
         // intersect their leaves together, so the long leaf code runs with many lanes active.
         while (w.ref != kWalkIdle) {
-            while (ref_is_node(w.ref)) walk_node(s, t_min, w, stack, stride);
-            if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, w, stack, stride);
+            while (ref_is_node(w.ref)) walk_node(s, t_min, lr, w, stack, stride);
+            if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, lr, w, stack, stride);
         }
     }
 }
@@ -573,16 +581,18 @@ template <uint32_t F>
 MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t min_lanes,
                         uint32_t node_lanes, uint32_t* stack, uint32_t stride, uint32_t& steps) {
     steps = 0;
+    LRay lr = make_lray(r);
+    if (w.ref != kWalkIdle) lr = walk_ray<F>(s, r, w.next - 1u);  // resuming inside hierarchy w.next - 1
     for (;;) {
-        if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w);
+        if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w, lr);
         while (w.ref != kWalkIdle && steps < budget) {
             while (ref_is_node(w.ref) && steps < budget) {
-                walk_node(s, t_min, w, stack, stride);
+                walk_node(s, t_min, lr, w, stack, stride);
                 ++steps;
                 if ((uint32_t)__popcll(__ballot(ref_is_node(w.ref))) < node_lanes) break;
             }
             if (ref_is_leaf(w.ref)) {
-                walk_leaf<F>(s, t_min, w, stack, stride);
+                walk_leaf<F>(s, t_min, lr, w, stack, stride);
                 ++steps;
             }
             // few lanes left walking: they stop here too and go on next iteration, together with the walks
