@@ -106,11 +106,13 @@ MIRT_DEV V3 ray_at(const Ray& r, float t) { return r.o + t * r.d; }
 struct LRay {
     Ray r;
     V3 rinv;
+    V3 nc;  // -origin * rinv: the distance to the plane at coordinate p of an axis is p * rinv + nc (walk_node)
 };
 MIRT_DEV LRay make_lray(const Ray& r) {
     LRay l;
     l.r = r;
     l.rinv = v3(fast_rcp(r.d.x), fast_rcp(r.d.y), fast_rcp(r.d.z));
+    l.nc = cmul(-r.o, l.rinv);
     return l;
 }
 
@@ -467,26 +469,30 @@ MIRT_DEV void walk_pop(Walk& w, const uint32_t* stack, uint32_t stride) {
     if (w.sp) w.ref = stack[(--w.sp) * stride];
 }
 
-// BVHNode::hit (aabb.rs:112-126) for one interior node: test both child boxes against [t_min,
-// closest] (the slab test of aabb.rs:43-60 with the far bound widened by 4 ulp, which covers the 1-ulp
-// reciprocals), continue with the nearer hit child and push the other. The twelve plane distances are
-// six packed subtract / multiply pairs. `stack` is this lane's column of an LDS array laid out
-// [level][lane] (stride = blockDim.x words): pushes and pops are conflict-free.
-MIRT_DEV void walk_node(const DevScene& s, float t_min, const LRay& lr, Walk& w, uint32_t* stack, uint32_t stride) {
+// BVHNode::hit (aabb.rs:112-126) for one interior node: test both child boxes against [t_min, closest] (the
+// slab test of aabb.rs:43-60), continue with the nearer hit child and push the other. The twelve plane
+// distances are six packed fused multiply-adds, t = p * rinv + (-origin * rinv): half the issue time of packed
+// subtract-then-multiply. That form errs by 2^-24 (|origin * rinv| + |t|) instead of a few ulp of t; the boxes
+// are stored padded by 2^-21 of the hierarchy's largest coordinate, which covers the first term for origins
+// within the scene, and the far bound is widened by 16 ulp, which covers the second, the first for origins far
+// outside (there |origin * rinv| is about |t|) and the 1-ulp reciprocals — so the test stays conservative and
+// the closest hit is unchanged. `stack` is this lane's column of an LDS array laid out [level][lane] (stride =
+// blockDim.x words): pushes and pops are conflict-free.
+MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w, uint32_t* stack, uint32_t stride) {
     const float4* q = reinterpret_cast<const float4*>(s.bvh_nodes + w.ref);
     const float4 a = q[0], b = q[1], c = q[2];
     const uint4 refs = reinterpret_cast<const uint4*>(q)[3];
-    const f32x2 oxy = {lr.r.o.x, lr.r.o.y}, ozz = {lr.r.o.z, lr.r.o.z};
-    const f32x2 rxy = {lr.rinv.x, lr.rinv.y}, rzz = {lr.rinv.z, lr.rinv.z};
-    const f32x2 l0 = (f32x2{a.x, a.y} - oxy) * rxy, h0 = (f32x2{a.z, a.w} - oxy) * rxy;
-    const f32x2 l1 = (f32x2{b.x, b.y} - oxy) * rxy, h1 = (f32x2{b.z, b.w} - oxy) * rxy;
-    const f32x2 z0 = (f32x2{c.x, c.y} - ozz) * rzz, z1 = (f32x2{c.z, c.w} - ozz) * rzz;
+    const f32x2 cxy = {nc.x, nc.y}, czz = {nc.z, nc.z};
+    const f32x2 rxy = {rinv.x, rinv.y}, rzz = {rinv.z, rinv.z};
+    const f32x2 l0 = __builtin_elementwise_fma(f32x2{a.x, a.y}, rxy, cxy), h0 = __builtin_elementwise_fma(f32x2{a.z, a.w}, rxy, cxy);
+    const f32x2 l1 = __builtin_elementwise_fma(f32x2{b.x, b.y}, rxy, cxy), h1 = __builtin_elementwise_fma(f32x2{b.z, b.w}, rxy, cxy);
+    const f32x2 z0 = __builtin_elementwise_fma(f32x2{c.x, c.y}, rzz, czz), z1 = __builtin_elementwise_fma(f32x2{c.z, c.w}, rzz, czz);
     const float tn0 = fmaxf(fmaxf(fminf(l0.x, h0.x), fminf(l0.y, h0.y)), fmaxf(fminf(z0.x, z0.y), t_min));
     const float tf0 = fminf(fminf(fmaxf(l0.x, h0.x), fmaxf(l0.y, h0.y)), fminf(fmaxf(z0.x, z0.y), w.closest));
     const float tn1 = fmaxf(fmaxf(fminf(l1.x, h1.x), fminf(l1.y, h1.y)), fmaxf(fminf(z1.x, z1.y), t_min));
     const float tf1 = fminf(fminf(fmaxf(l1.x, h1.x), fmaxf(l1.y, h1.y)), fminf(fmaxf(z1.x, z1.y), w.closest));
     // (the missing second child of a single-leaf tree has no reference; its empty box would pass the test)
-    const bool hit0 = tn0 <= tf0 * 1.0000004f, hit1 = (tn1 <= tf1 * 1.0000004f) & (refs.y != kWalkIdle);
+    const bool hit0 = tn0 <= tf0 * 1.000002f, hit1 = (tn1 <= tf1 * 1.000002f) & (refs.y != kWalkIdle);
     if (hit0 && hit1) {
         const bool first0 = tn0 <= tn1;
         w.ref = first0 ? refs.x : refs.y;
@@ -560,7 +566,7 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
         // descend through interior nodes until each of them holds a leaf (or is done), then all
         // intersect their leaves together, so the long leaf code runs with many lanes active.
         while (w.ref != kWalkIdle) {
-            while (ref_is_node(w.ref)) walk_node(s, t_min, lr, w, stack, stride);
+            while (ref_is_node(w.ref)) walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride);
             if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, lr, w, stack, stride);
         }
     }
@@ -587,7 +593,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
         if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w, lr);
         while (w.ref != kWalkIdle && steps < budget) {
             while (ref_is_node(w.ref) && steps < budget) {
-                walk_node(s, t_min, lr, w, stack, stride);
+                walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride);
                 ++steps;
                 if ((uint32_t)__popcll(__ballot(ref_is_node(w.ref))) < node_lanes) break;
             }

@@ -465,7 +465,13 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
             // leaf test costs a step whether or not the ray comes near the second sphere; the box test that
             // replaces it is cheaper).
             if (records_per_object > 16u) return bad("entry " + std::to_string(e) + ": prims_per_object is limited to 16");
-            BvhBuilder builder(nodes, slots, 32, records_per_object);
+            // Box padding for walk_node's fused plane distances: 2^-21 of the largest coordinate magnitude of the
+            // hierarchy (the evaluation errs by 2^-24 |origin| in position for origins inside the scene; farther
+            // origins are covered by the relative widening of the far bound).
+            float reach = 0.f;
+            for (const BuildObject& o : objs)
+                for (int a = 0; a < 3; ++a) reach = std::max(reach, std::max(std::fabs(o.lo[a]), std::fabs(o.hi[a])));
+            BvhBuilder builder(nodes, slots, 32, records_per_object, std::isfinite(reach) ? reach * 4.76837158e-7f : 0.f);
             q.bvh_root = builder.build(objs);
             slot_is_cuboid.resize(slots.size(), cuboids ? 1 : 0);  // marks the slots this entry added
             // the hit record of a BVH member is rebuilt with the entry's transform
