@@ -1,16 +1,28 @@
-"""Benchmark of the hot path: Msamples/s on the 1920x1080 Cornell box, 1024 spp, depth 50.
+"""Benchmark of the hot path: Msamples/s of the per-pixel sample loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 1|2|3|4|5] [--scaling weak|strong]
 
-A step is one full pass of the per-pixel sample loop over one frame (W*H*spp primary paths) followed by
-the RGBA8 resolve, with scene and camera already resident on the GPU. With N > 1 (launched by
-torch.distributed.run, one rank per GPU) every rank renders the whole frame for its own range of `spp`
-samples (weak scaling: N*spp samples per pixel in total), the float4 accumulation buffers are summed onto
-rank 0 with one RCCL reduce, and rank 0 resolves. Rank 0 prints ONE JSON line.
+Default workload (config 2, the one the metric is quoted on): Cornell box 1920x1080, 1024 spp, depth 50.
+A step is one full pass of the sample loop over one frame (W*H*spp primary paths) followed by the RGBA8
+resolve, with scene and camera already resident on the GPU.
+
+With N > 1 there is one process per GPU. Started by torch.distributed.run (RANK / WORLD_SIZE in the
+environment) this file is a rank; started plainly with --gpus N it launches the N ranks itself, as child
+processes, before anything in this process touches a GPU. Every rank renders the whole frame for its own range
+of samples (weak: `spp` samples per rank, N*spp per pixel in total; strong: `spp` split over the ranks), the
+float4 accumulation buffers are summed onto rank 0 by the library's RCCL reduce (ncclReduce over xGMI, on the
+render stream), and rank 0 resolves. torch.distributed (gloo) is the control plane only: it carries the RCCL id
+and the barriers. Rank 0 prints ONE JSON line.
+
+Other configurations of the metric's family (parity-tested, reported for their rooflines):
+  1  random 400x225, 10 spp, depth 50            3  final 1920x1080, 256 spp, depth 50
+  4  cornell 3840x2160, 16384 spp, strong split   5  random num=500 (1 M spheres) 3840x2160, 1 spp per pass, depth 10
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -18,35 +30,72 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FLOP_PER_SEGMENT = 400.0       # algorithmic FLOP of one Cornell path segment (12 rect tests x 12 + sphere 30 +
-                               # instance transform 15 + diffuse shade with the 2-light mixture pdf 200)
-# MI355X FP32 vector peak (spec, packed v_pk_fma_f32): the `peak` of the roofline object. Plain v_fma_f32 code was
-# measured at 111.8 TFLOP/s (scripts/calib/valu_count.hip: a wave64 v_fma_f32 per 2.8 cycles and SIMD with 8
-# waves resident); the render kernel is scalar-per-lane code except for the rect pairs, so the fraction of that
-# measured rate is reported beside `frac`.
+# Algorithmic FLOP per unit of work (fixed convention: add = mul = compare-select = 1, fma = 2, div = sqrt = 1):
+# rect test 12 (geo.rs:198-204), sphere test 30 (geo.rs:90-105), box test 24 (aabb.rs:50-59), instance transform
+# in + out 15, diffuse shade with the mixture pdf 200 (renderer.rs:207-221). A Cornell segment is 12 rects +
+# 1 sphere + 1 transform + shade = 389, rounded to 400 by the convention the metric was defined with.
+FLOP_RECT, FLOP_SPHERE, FLOP_BOX, FLOP_TRANSFORM, FLOP_SHADE = 12.0, 30.0, 24.0, 15.0, 200.0
+FLOP_PER_CORNELL_SEGMENT = 400.0
+# MI355X FP32 vector peak (packed v_pk_fma_f32): the `peak` of the roofline object. Plain v_fma_f32 code was
+# measured at 111.8 TFLOP/s (scripts/calib/valu_count.hip); the fraction of that rate is reported beside `frac`.
 PEAK_FP32_VALU_TFLOPS = 157.3
 UNPACKED_FP32_TFLOPS = 111.8
-# HBM bytes of one launch of the render kernel on the default workload, from rocprofv3 PMC passes
-# (profiles/r1/cornell_1080p_1024spp_v4_hbm_traffic_pmc.txt): 2 x FETCH_SIZE (gfx950 counts half of a wide read)
-# + WRITE_SIZE, in KiB. The persistent kernel writes one float4 per pixel and sample chunk (16 chunks x 33.2 MB)
-# and reads next to nothing; the pass that adds the chunks (reduce_chunks_kernel, 0.1 ms) reads them back once.
-MEASURED_TRAFFIC_BYTES = {("cornell", 1920, 1080, 1024): (2 * 6922.375 + 544951.65625) * 1024}
+# HBM bytes per launch of the render kernel, from rocprofv3 PMC passes of this same command (separate runs, as the
+# counters demand); the file names the profile each figure comes from.
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "hbm_traffic.json")
 
-def cpu_baseline(scene, width, height, depth, target_seconds=12.0):
-    """The oracle (CPU restatement of the reference renderer) on this host's cores, on a bounded sample of
-    the same workload: the same frame at a reduced sample count."""
+CONFIGS = {
+    1: dict(scene="random", width=400, height=225, spp=10, depth=50),
+    2: dict(scene="cornell", width=1920, height=1080, spp=1024, depth=50),
+    3: dict(scene="final", width=1920, height=1080, spp=256, depth=50),
+    4: dict(scene="cornell", width=3840, height=2160, spp=16384, depth=50, scaling="strong"),
+    5: dict(scene="random", width=3840, height=2160, spp=1, depth=10, random_num=500),
+}
+
+
+def cpu_baseline(scene, width, height, depth, random_num, target_seconds=10.0):
+    """The oracle (CPU restatement of the reference renderer, rows handed to threads as rayon does) on this host,
+    on a bounded sample of the same workload: the same scene and depth on a frame of the same shape at a sample
+    count (and, for the million-sphere scene, a size) that fits the time budget. Timed at two thread counts — every
+    CPU the process may run on, and 16 — because a container may show more CPUs than it may use; the faster one is
+    reported with its thread count."""
     import oracle
-    threads = min(os.cpu_count() or 1, 16)
-    r = oracle.OracleRenderer(scene, width, height)
-    t0 = time.time()
-    r.render_sums(1, depth, seed=0, threads=threads)
-    dt1 = time.time() - t0
-    spp = max(1, min(16, int(target_seconds / max(dt1, 1e-3))))
-    t0 = time.time()
-    r.render_sums(spp, depth, seed=1, threads=threads)
-    dt = time.time() - t0
-    return {"value": width * height * spp / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{scene} {width}x{height}, {spp} spp, depth {depth}, {dt:.1f} s"}
+    try:
+        visible = len(os.sched_getaffinity(0))
+    except AttributeError:
+        visible = os.cpu_count() or 1
+    w, h = width, height
+    while w * h > 1920 * 1080 or (random_num > 11 and w * h > 64 * 36):   # a linear scan of 10^6 spheres per ray
+        w, h = max(w // 2, 2), max(h // 2, 2)
+    r = oracle.OracleRenderer(scene, w, h, random_num=random_num)
+    best = None
+    for threads in sorted({min(visible, 256), min(visible, 16)}, reverse=True):
+        t0 = time.time()
+        r.render_sums(1, depth, seed=0, threads=threads)
+        dt1 = time.time() - t0
+        spp = max(1, min(16, int(target_seconds / max(dt1, 1e-3))))
+        t0 = time.time()
+        r.render_sums(spp, depth, seed=1, threads=threads)
+        dt = time.time() - t0
+        v = w * h * spp / dt / 1e6
+        if best is None or v > best["value"]:
+            best = {"value": v, "unit": "Msamples/s", "cores": threads, "kind": "port",
+                    "sample": f"{scene} {w}x{h}, {spp} spp, depth {depth}, {dt:.1f} s on {threads} threads",
+                    "cpus_visible": visible, "os_cpu_count": os.cpu_count()}
+    return best
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n):
+    """--gpus N without a launcher: start the N ranks as children of this process (which has not touched a GPU)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
@@ -54,90 +103,122 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scene", default="cornell")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spp", type=int, default=1024)
-    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--scene")
+    ap.add_argument("--width", type=int)
+    ap.add_argument("--height", type=int)
+    ap.add_argument("--spp", type=int)
+    ap.add_argument("--depth", type=int)
+    ap.add_argument("--random-num", type=int, dest="random_num")
+    ap.add_argument("--scaling", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the control flow)")
     args = ap.parse_args()
+    cfg = dict(scaling="weak", random_num=11)
+    cfg.update(CONFIGS[args.config])
+    for k in ("scene", "width", "height", "spp", "depth", "random_num", "scaling"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
 
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+
+    import torch  # before the library: one HIP runtime per process, whichever is loaded first serves both
     import ray_tracing_amd as rt
-    from ray_tracing_amd.distributed import reduce_accum, weak_range
+    from ray_tracing_amd.distributed import join_comm, sample_range, weak_range
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        local_rank %= max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(local_rank)
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(args.backend)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        dist.init_process_group("gloo")     # control plane; the accumulation buffers travel over the library's RCCL reduce
+    n_dev = max(torch.cuda.device_count(), 1)
+    device = local_rank % n_dev
 
-    W, H, spp = args.width, args.height, args.spp
-    ctx = rt.Context(local_rank)
-    scene = rt.select_scene(args.scene)
+    W, H, spp, depth, scene_name = cfg["width"], cfg["height"], cfg["spp"], cfg["depth"], cfg["scene"]
+    ctx = rt.Context(device)
+    scene = rt.select_scene(scene_name, random_num=cfg["random_num"])
     ctx.scene_upload(scene)
-    ctx.camera_set(rt.Camera.select_camera(W / H, args.scene))
-    accum = torch.zeros(H * W * 4, dtype=torch.float32, device=dev)     # caller-owned, reducible by RCCL
-    frame = torch.zeros(H * W * 4, dtype=torch.uint8, device=dev)
-    torch.cuda.synchronize()   # the fills above run on torch's stream, the renderer on its own
+    ctx.camera_set(rt.Camera.select_camera(W / H, scene_name))
+    if world > 1:
+        join_comm(ctx, rank, world)
+    begin, count = sample_range(spp, world, rank) if cfg["scaling"] == "strong" else weak_range(spp, rank)
+    total_spp = spp if cfg["scaling"] == "strong" else spp * world
+    jitter = total_spp != 1                 # renderer.rs:175
 
     def step():
-        ctx.frame_begin(W, H, accum.data_ptr())
-        begin, count = weak_range(spp, rank)
-        ctx.render(count, args.depth, spp_begin=begin, seed=0, jitter=True)
+        ctx.frame_begin(W, H)
+        ctx.render(count, depth, spp_begin=begin, seed=0, jitter=jitter)
         if world > 1:
-            ctx.synchronize()                       # the render runs on the library's own stream
-            reduce_accum(accum, dst=0)              # RCCL sum of the float4 buffers onto rank 0
-            torch.cuda.synchronize()
+            ctx.comm_reduce(0)              # RCCL sum of the float4 buffers onto rank 0, behind the render on its stream
         if rank == 0:
-            ctx.resolve_rgba8_device(frame.data_ptr(), frame.numel())
+            ctx.resolve_rgba8_device(None, W * H * 4)
         ctx.synchronize()
 
     def barrier():
+        ctx.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-        ctx.synchronize()
 
     for _ in range(args.warmup):
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, segments, launches = 0.0, 0, 0
+    kernel_ms, launches = 0.0, 0
+    tot = {k: 0 for k in ("segments", "bvh_node_steps", "bvh_sphere_tests", "bvh_rect_tests")}
+    st = {}
     for _ in range(args.steps):
         step()
-        st = ctx.stats()                            # HIP-event time of this step's render launches
+        st = ctx.stats()                    # HIP-event time of this step's render launches, on the render stream
         kernel_ms += st["kernel_ms"]
-        segments += st["segments"]
         launches += st["kernel_launches"]
+        for k in tot:
+            tot[k] += st[k]
+        if st["device_faults"]:
+            raise SystemExit(f"device faults {st['device_faults']}")
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        samples_per_step = W * H * spp * world
+        samples_per_step = W * H * total_spp
         value = samples_per_step * args.steps / elapsed / 1e6
-        achieved = FLOP_PER_SEGMENT * segments / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        seg = max(tot["segments"], 1)
+        n_box, n_sph, n_rect = 2.0 * tot["bvh_node_steps"] / seg, tot["bvh_sphere_tests"] / seg, tot["bvh_rect_tests"] / seg
+        per_segment = {"boxes": n_box, "spheres": n_sph + st["list_spheres"], "rects": n_rect + st["list_rects"],
+                       "transforms": st["list_transforms"]}
+        if scene_name == "cornell":
+            flop_per_segment = FLOP_PER_CORNELL_SEGMENT
+        else:
+            flop_per_segment = (FLOP_BOX * per_segment["boxes"] + FLOP_SPHERE * per_segment["spheres"] + FLOP_RECT * per_segment["rects"]
+                                + FLOP_TRANSFORM * per_segment["transforms"] + FLOP_SHADE)
+        achieved = flop_per_segment * tot["segments"] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        traffic, traffic_src = None, None
+        try:
+            with open(TRAFFIC_FILE) as f:
+                entry = json.load(f).get(f"{scene_name} {W}x{H} {count}spp depth{depth}")
+            if entry:
+                traffic, traffic_src = entry["bytes_per_launch"], entry["profile"]
+        except (OSError, ValueError):
+            pass
         out = {
             "metric": "Msamples/sec at 1920x1080 Cornell box; % of FP32-VALU/HBM roofline",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": cfg["scaling"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.scene} {W}x{H}, {spp} spp per GPU, max depth {args.depth}, light+cosine mixture pdf",
-                       "samples_per_step": samples_per_step, "parallelism": f"spp-range x{world}" + (" + RCCL reduce" if world > 1 else "")},
+            "config": {"workload": f"{scene_name} {W}x{H}, {spp} spp {'in total' if cfg['scaling'] == 'strong' else 'per GPU'}, max depth {depth}"
+                                   + (", light+cosine mixture pdf" if scene_name == "cornell" else "")
+                                   + (f", random_num {cfg['random_num']} ({scene.desc.n_prims} spheres)" if cfg["random_num"] != 11 else ""),
+                       "config_id": args.config, "samples_per_step": samples_per_step,
+                       "parallelism": f"spp-range x{world}" + (" + RCCL reduce" if world > 1 else ""), "rccl_ranks": ctx.comm_ranks()},
             # compute-bound, not HBM-bound: of the two roofline categories this is the arithmetic one. A path tracer
             # has no matrix products, so the arithmetic runs on the vector ALUs; for f32 the vector peak and the
             # dense MFMA peak of the MI355X are the same 157.3 TFLOP/s.
@@ -145,16 +226,18 @@ def main():
                          "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "frac_of_unpacked_fma_rate": achieved / UNPACKED_FP32_TFLOPS,
-                         "traffic": MEASURED_TRAFFIC_BYTES.get((args.scene, W, H, spp)), "traffic_unit": "bytes per launch (PMC, separate run)",
-                         "kernel": "render_queue_kernel", "avg_launch_ms": kernel_ms / max(launches, 1),
-                         "segments_per_sample": segments / (W * H * spp * args.steps),
-                         "gsegments_per_s": segments / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
-                         "flop_per_segment": FLOP_PER_SEGMENT},
+                         "traffic": traffic, "traffic_unit": "bytes per launch (PMC, separate run)", "traffic_profile": traffic_src,
+                         "kernel": "render_queue_kernel" if st.get("kernel_used") == rt.KERNEL_QUEUE else "render_fused_kernel",
+                         "avg_launch_ms": kernel_ms / max(launches, 1),
+                         "segments_per_sample": tot["segments"] / (W * H * count * args.steps),
+                         "gsegments_per_s": tot["segments"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
+                         "flop_per_segment": flop_per_segment, "tests_per_segment": per_segment},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.scene, W, H, args.depth)
+            out["cpu_baseline"] = cpu_baseline(scene_name, W, H, depth, cfg["random_num"])
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

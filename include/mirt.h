@@ -29,6 +29,8 @@ extern "C" {
 #define MIRT_ERR_HIP (-2)      /* a HIP runtime call failed */
 #define MIRT_ERR_STATE (-3)    /* call order: no scene / camera / frame yet */
 #define MIRT_ERR_NO_DEVICE (-4)
+#define MIRT_ERR_DEVICE (-5)   /* the kernels reported an internal fault (mirt_stats.device_faults) */
+#define MIRT_ERR_COMM (-6)     /* an RCCL call failed, or librccl could not be loaded */
 
 typedef struct mirt_ctx mirt_ctx;
 
@@ -162,7 +164,18 @@ typedef struct mirt_stats {
     uint64_t lane_slots;   /* fused kernel: 64 x loop iterations summed over waves; segments / lane_slots =
                               share of lane-iterations that traced a segment (the rest idled in a wave whose
                               other lanes had longer paths) */
+    /* Algorithmic work of the hierarchy walks of the persistent kernel since mirt_frame_begin, counted per lane that
+     * took the step: interior nodes visited (two child boxes each), leaf spheres and leaf rects intersected (a cuboid
+     * is six). With the list_* fields — what one scan of the world's list entries tests, i.e. per segment — this
+     * prices a segment: 24 FLOP per box, 30 per sphere, 12 per rect, 15 per instance transform. */
+    uint64_t bvh_node_steps, bvh_sphere_tests, bvh_rect_tests;
+    uint32_t list_rects, list_spheres, list_transforms;
+    uint32_t device_faults;    /* MIRT_FAULT_* bits the kernels raised since mirt_frame_begin; 0 in a correct run */
+    uint32_t bvh_deepest_leaf; /* level of the deepest leaf of the scene's hierarchies (root node = 1); the traversal
+                                  stack holds 32 entries and a leaf at level L needs L - 1 */
 } mirt_stats;
+#define MIRT_FAULT_STACK_OVERFLOW 1u /* a hierarchy walk found its traversal stack full and dropped a subtree */
+#define MIRT_FAULT_STALE_CHUNK 2u    /* a (pixel, sample chunk) work item of the persistent kernel was never stored */
 
 /* ---- entry points --------------------------------------------------------------------------- */
 
@@ -190,9 +203,11 @@ int mirt_render(mirt_ctx* ctx, const mirt_render_params* p);
 
 /* renderer.rs:109-116 and the row flip of :97: mean, clamp [0,0.999], sqrt, *256, truncate; alpha
  * 0xff; top row first. frame is a HOST buffer of len == width*height*4 bytes (checked, mirrors the
- * assert of renderer.rs:65). Blocks until done. */
+ * assert of renderer.rs:65). Blocks until done. Returns MIRT_ERR_DEVICE (frame still written) when the
+ * kernels raised a fault bit since mirt_frame_begin — the reference would have panicked. */
 int mirt_resolve_rgba8(mirt_ctx* ctx, uint8_t* frame, size_t len);
-/* The same into a DEVICE buffer, asynchronous on the context's stream. */
+/* The same into a DEVICE buffer, asynchronous on the context's stream. frame_device may be NULL: the frame then
+ * stays in a device buffer the library keeps (a viewer that only presents it, a benchmark). */
 int mirt_resolve_rgba8_device(mirt_ctx* ctx, uint8_t* frame_device, size_t len);
 
 /* Copy the accumulation buffer to the host (n == width*height*4 floats). Blocks. */
@@ -212,6 +227,23 @@ int mirt_first_hit(mirt_ctx* ctx, const mirt_ray* rays, size_t n, uint32_t seed,
 /* ray_color (renderer.rs:197) for n host rays, one un-sanitised sample each: ray i uses
  * (pixel = i, sample). out = n*3 floats. */
 int mirt_ray_color(mirt_ctx* ctx, const mirt_ray* rays, size_t n, uint32_t sample, uint32_t max_depth, uint32_t seed, float* out);
+
+/* ---- the exchange step of the multi-GPU split --------------------------------------------------
+ * The reference keeps its parallelism inside draw() (rayon tasks over rows, renderer.rs:69-72). With GPUs as the
+ * workers the split is by sample range: context g renders samples [g*S, (g+1)*S) of every pixel (spp_begin /
+ * spp_count of mirt_render) into its own accumulation buffer, and ONE sum of those buffers onto the root follows —
+ * an RCCL ncclReduce(sum, float, width*height*4) over xGMI, enqueued on each context's own stream behind its
+ * render (asynchronous; resolve on the root afterwards). librccl is loaded on first use.
+ *
+ * One process, n contexts on n different devices, every frame begun with the same size: */
+int mirt_reduce(mirt_ctx** ctxs, int n, int root);
+/* One process per GPU: some rank makes an id, the caller carries its bytes to all ranks by whatever channel it
+ * has (MPI, torch.distributed, a file), every rank joins with it, then every rank calls mirt_comm_reduce. */
+#define MIRT_COMM_ID_BYTES 128
+int mirt_comm_unique_id(uint8_t id[MIRT_COMM_ID_BYTES]);
+int mirt_comm_init_rank(mirt_ctx* ctx, int n_ranks, int rank, const uint8_t id[MIRT_COMM_ID_BYTES]);
+int mirt_comm_reduce(mirt_ctx* ctx, int root);
+int mirt_comm_ranks(const mirt_ctx* ctx); /* ranks of the communicator the context belongs to, 0 = none */
 
 int mirt_synchronize(mirt_ctx* ctx);
 int mirt_get_stats(mirt_ctx* ctx, mirt_stats* out);

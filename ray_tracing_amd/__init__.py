@@ -25,6 +25,7 @@ EXPORTS = [
     "mirt_render", "mirt_resolve_rgba8", "mirt_resolve_rgba8_device", "mirt_read_accum", "mirt_write_accum",
     "mirt_accum_device_ptr",
     "mirt_first_hit", "mirt_ray_color", "mirt_synchronize", "mirt_get_stats", "mirt_philox4x32_10",
+    "mirt_reduce", "mirt_comm_unique_id", "mirt_comm_init_rank", "mirt_comm_reduce", "mirt_comm_ranks",
     "mirt_host_select_scene", "mirt_host_scene_desc", "mirt_host_scene_free", "mirt_host_select_camera",
     "mirt_host_draw", "mirt_host_save_png", "mirt_host_last_error",
 ]
@@ -47,7 +48,10 @@ class mirt_render_params(C.Structure):
 
 class mirt_stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("kernel_ms", C.c_double),
-                ("kernel_launches", C.c_uint32), ("kernel_used", C.c_uint32), ("lane_slots", C.c_uint64)]
+                ("kernel_launches", C.c_uint32), ("kernel_used", C.c_uint32), ("lane_slots", C.c_uint64),
+                ("bvh_node_steps", C.c_uint64), ("bvh_sphere_tests", C.c_uint64), ("bvh_rect_tests", C.c_uint64),
+                ("list_rects", C.c_uint32), ("list_spheres", C.c_uint32), ("list_transforms", C.c_uint32),
+                ("device_faults", C.c_uint32), ("bvh_deepest_leaf", C.c_uint32)]
 
 
 class mirt_prim(C.Structure):
@@ -136,6 +140,11 @@ def lib():
         L.mirt_get_stats.argtypes = [vp, C.POINTER(mirt_stats)]
         L.mirt_philox4x32_10.argtypes = [vp, vp, vp]
         L.mirt_philox4x32_10.restype = None
+        L.mirt_reduce.argtypes = [C.POINTER(vp), C.c_int, C.c_int]
+        L.mirt_comm_unique_id.argtypes = [vp]
+        L.mirt_comm_init_rank.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.mirt_comm_reduce.argtypes = [vp, C.c_int]
+        L.mirt_comm_ranks.argtypes = [vp]
         L.mirt_host_select_scene.argtypes = [C.c_char_p, u32, C.c_int, vp, u32, u32, C.POINTER(vp)]
         L.mirt_host_scene_desc.argtypes = [vp]
         L.mirt_host_scene_desc.restype = C.POINTER(mirt_scene_desc)
@@ -323,7 +332,38 @@ class Context:
         s = mirt_stats()
         self._check(lib().mirt_get_stats(self._c, C.byref(s)))
         return {"samples": s.samples, "segments": s.segments, "kernel_ms": s.kernel_ms,
-                "kernel_launches": s.kernel_launches, "kernel_used": s.kernel_used, "lane_slots": s.lane_slots}
+                "kernel_launches": s.kernel_launches, "kernel_used": s.kernel_used, "lane_slots": s.lane_slots,
+                "device_faults": s.device_faults, "bvh_deepest_leaf": s.bvh_deepest_leaf,
+                "bvh_node_steps": s.bvh_node_steps, "bvh_sphere_tests": s.bvh_sphere_tests, "bvh_rect_tests": s.bvh_rect_tests,
+                "list_rects": s.list_rects, "list_spheres": s.list_spheres, "list_transforms": s.list_transforms}
+
+    # ---- the exchange step of the sample-range split (RCCL sum of the accumulation buffers onto `root`)
+    def comm_init_rank(self, n_ranks, rank, comm_id):
+        """Join the communicator identified by the 128 bytes of `comm_id` (made by comm_unique_id() on one rank)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(comm_id))
+        self._check(lib().mirt_comm_init_rank(self._c, n_ranks, rank, buf))
+
+    def comm_reduce(self, root=0):
+        self._check(lib().mirt_comm_reduce(self._c, root))
+
+    def comm_ranks(self):
+        return lib().mirt_comm_ranks(self._c)
+
+
+def comm_unique_id():
+    """128 bytes that identify a new communicator; carry them to every rank and pass them to Context.comm_init_rank."""
+    buf = (C.c_uint8 * 128)()
+    if lib().mirt_comm_unique_id(buf) != MIRT_OK:
+        raise MirtError(lib().mirt_last_error(None).decode())
+    return bytes(buf)
+
+
+def reduce(contexts, root=0):
+    """mirt_reduce: sum the accumulation buffers of contexts on different devices of this process onto contexts[root]."""
+    arr = (C.c_void_p * len(contexts))(*[c._c for c in contexts])
+    rc = lib().mirt_reduce(arr, len(contexts), root)
+    if rc != MIRT_OK:
+        raise MirtError(f"mirt error {rc}: {lib().mirt_last_error(contexts[0]._c).decode()}")
 
 
 class Renderer:

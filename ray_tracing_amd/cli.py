@@ -17,7 +17,7 @@ import time
 import numpy as np
 
 import ray_tracing_amd as rt
-from ray_tracing_amd.distributed import reduce_accum, sample_range
+from ray_tracing_amd.distributed import join_comm, sample_range
 
 WIDTH, HEIGHT = 1920, 1080  # lib.rs:42-43
 
@@ -60,10 +60,10 @@ def image_mode(argv=None):
 
     dist = None
     if world > 1:
-        import torch
         import torch.distributed as dist
-        torch.cuda.set_device(device)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        dist.init_process_group("gloo")      # control plane only; the buffers travel over the library's RCCL reduce
+        if a.checkpoint:
+            raise SystemExit("--checkpoint saves one accumulation buffer and is for single-GPU runs; drop it or run one process")
 
     scene = rt.select_scene(a.scene, scene_seed=a.scene_seed)
     camera = rt.Camera.select_camera(width / height, a.scene)   # cli.rs:25
@@ -71,16 +71,12 @@ def image_mode(argv=None):
     ctx.scene_upload(scene)
     ctx.camera_set(camera)
 
-    accum_t = None
     if world > 1:
-        import torch
-        accum_t = torch.zeros(height * width * 4, dtype=torch.float32, device=f"cuda:{device}")
-        torch.cuda.synchronize()
-        ctx.frame_begin(width, height, accum_t.data_ptr())
-    else:
-        ctx.frame_begin(width, height)
+        join_comm(ctx, rank, world)
+    ctx.frame_begin(width, height)
 
-    tag = f"{a.scene}/{a.scene_seed}/{a.seed}/{a.max_depth}/{world}"
+    jitter = a.sample_count != 1   # renderer.rs:175
+    tag = f"{a.scene}/{a.scene_seed}/{a.seed}/{a.max_depth}/{world}/{width}x{height}/{'jitter' if jitter else 'centre'}"
     done = 0
     if world == 1:
         saved, done = _load_checkpoint(a.checkpoint, (height, width, 4), tag)
@@ -90,7 +86,6 @@ def image_mode(argv=None):
 
     begin, count = sample_range(a.sample_count, world, rank)
     step = a.pass_spp if a.pass_spp > 0 else max(count, 1)
-    jitter = a.sample_count != 1   # renderer.rs:175
     t0 = time.time()
     local_done = min(done, count)
     while local_done < count:
@@ -106,9 +101,8 @@ def image_mode(argv=None):
             os.replace(tmp, a.checkpoint)
     ctx.synchronize()
     if world > 1:
-        reduce_accum(accum_t, dst=0)
-        import torch
-        torch.cuda.synchronize()
+        ctx.comm_reduce(0)                  # RCCL sum of the float4 buffers onto rank 0, behind the render on its stream
+        ctx.synchronize()
     if rank == 0:
         frame = ctx.resolve_rgba8()
         dt = time.time() - t0

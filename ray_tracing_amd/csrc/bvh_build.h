@@ -5,6 +5,7 @@
 // hit (ties between equal-t leaves aside, which the reference resolves by tree shape too).
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <thread>
@@ -55,6 +56,9 @@ class BvhBuilder {
         return (uint32_t)node0;
     }
 
+    // Level of the deepest leaf built so far, the root node being level 1 (its children are level 2).
+    int deepest_leaf() const { return deepest_.load(); }
+
    private:
     struct Ref {
         uint32_t c, n;
@@ -66,6 +70,7 @@ class BvhBuilder {
     int max_depth_;
     uint32_t ppo_;
     float pad_;
+    std::atomic<int> deepest_{0};
 
     void set_child(DevBvhNode& nd, int which, const Ref& r) const {
         const uint32_t ref = r.n ? (0x80000000u | ((r.n - 1u) << 27) | r.c) : r.c;
@@ -106,6 +111,8 @@ class BvhBuilder {
             }
         size_t n = end - begin;
         if (n == 1) {
+            int seen = deepest_.load();
+            while (seen < depth && !deepest_.compare_exchange_weak(seen, depth)) {}
             r.c = (uint32_t)slot;
             r.n = ppo_;
             for (uint32_t q = 0; q < ppo_; ++q) slots_[slot + q] = objs[begin].first_prim + q;

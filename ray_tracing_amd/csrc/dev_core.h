@@ -421,13 +421,23 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
 // whose walk ended early need not wait for the longest one, was measured and lost 5-20 %: a shading
 // round costs as much as ~25 node steps, and every extra round runs that code again.)
 // ---------------------------------------------------------------------------------------------
-constexpr int kBvhStackDepth = 32;
 constexpr uint32_t kWalkIdle = 0xffffffffu;   // no reference: the walk is over
 constexpr uint32_t kRefLeaf = 0x80000000u;    // leaf reference: bit 31, (records - 1) << 27, first record
 constexpr uint32_t kRefLeafIndexMask = (1u << 27) - 1u;
 
 MIRT_DEV bool ref_is_leaf(uint32_t ref) { return ref != kWalkIdle && (ref & kRefLeaf); }
 MIRT_DEV bool ref_is_node(uint32_t ref) { return !(ref & kRefLeaf); }
+
+// What the walks of a wave have cost, counted per lane that took the step (wave-uniform sums kept in scalar
+// registers while a walk runs: one s_bcnt1 of the exec mask per step). walk_some() adds them to the wave's three
+// words in LDS when its turn ends, so nothing stays in registers over the shading code; the render kernel adds
+// the words to the statistics block once per wave. Where nobody reads them the counters fold away.
+struct WalkCost {
+    uint32_t node_steps;    // interior nodes visited (two child boxes tested each)
+    uint32_t sphere_tests;  // leaf spheres intersected
+    uint32_t rect_tests;    // leaf rects intersected (six per cuboid record)
+};
+MIRT_DEV uint32_t lanes_here() { return (uint32_t)__popcll(__ballot(true)); }
 
 struct Walk {
     uint32_t ref;    // current reference (interior node index or leaf run) or kWalkIdle
@@ -443,7 +453,19 @@ template <uint32_t F>
 MIRT_DEV LRay walk_ray(const DevScene& s, const Ray& r, uint32_t k) {
     const DevEntry& en = s.entries[s.bvh_entries[k]];
     // 1-ulp reciprocals; walk_node() widens the far bound by more than that
-    return make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
+    LRay l = make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
+    // A direction component of (+-)0 has the reciprocal +-inf, and walk_node's  p * rinv + (-origin * rinv)  would
+    // be inf - inf = NaN for every plane on the far side of the origin: min / max drop the NaN and a slab the ray
+    // lies inside is taken for one it misses. With the reciprocal limited to +-2^100 the two products stay finite
+    // for any coordinate below 2^27 and keep their signs, so an axis-parallel ray sees (-huge, +huge) for a slab
+    // that contains it and two huge distances of one sign otherwise, which is what aabb.rs:43-60 computes with
+    // infinities. (The leaf tests read the same reciprocal: a rect parallel to the ray gets a huge finite t
+    // instead of inf or NaN and misses either way, since one of its two in-plane coordinates moves with t.)
+    constexpr float kRinvMax = 1.2676506e30f;
+    l.rinv = v3(__builtin_amdgcn_fmed3f(l.rinv.x, -kRinvMax, kRinvMax), __builtin_amdgcn_fmed3f(l.rinv.y, -kRinvMax, kRinvMax),
+                __builtin_amdgcn_fmed3f(l.rinv.z, -kRinvMax, kRinvMax));
+    l.nc = cmul(-l.r.o, l.rinv);
+    return l;
 }
 
 // Number of hierarchies the ray has to walk. A ray with a NaN component hits no primitive (see
@@ -496,7 +518,10 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w,
     if (hit0 && hit1) {
         const bool first0 = tn0 <= tn1;
         w.ref = first0 ? refs.x : refs.y;
-        if (w.sp < (uint32_t)kBvhStackDepth) stack[(w.sp++) * stride] = first0 ? refs.y : refs.x;
+        // (the host checks the depth of every hierarchy it builds against the stack at upload; a full stack here
+        // means that promise was broken, and the dropped child is reported instead of silently missed)
+        if (w.sp < s.stack_limit) stack[(w.sp++) * stride] = first0 ? refs.y : refs.x;
+        else atomicOr(s.fault, (uint32_t)FAULT_STACK_OVERFLOW);
     } else if (hit0) {
         w.ref = refs.x;
     } else if (hit1) {
@@ -531,11 +556,12 @@ MIRT_DEV bool leaf_rec_hit(const DevScene& s, const DevLeafRec& rec, const LRay&
 
 // The records of one leaf, in object order (a later record wins a tie, as in ray.rs:123-133).
 template <uint32_t F>
-MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w, const uint32_t* stack, uint32_t stride) {
+MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w, const uint32_t* stack, uint32_t stride, WalkCost& cost) {
     const uint32_t first = w.ref & kRefLeafIndexMask, n = ((w.ref >> 27) & 15u) + 1u;
     for (uint32_t j = 0; j < n; ++j) {
         const DevLeafRec& rec = s.bvh_leaves[first + j];
         if ((F & F_RECT) && (rec.code_inst & 0xffu) == SC_CUBOID) {
+            cost.rect_tests += 6u * lanes_here();
             // Cuboid (geo.rs:245-289): its six rects in list order — XY at z lo / hi, XZ at y lo / hi, YZ at
             // x lo / hi — from the two corners f = (lo.xyz, hi.xyz); ids prim .. prim + 5
             const float lx = rec.f[0], ly = rec.f[1], lz = rec.f[2], hx = rec.f[3], hy = rec.f[4], hz = rec.f[5];
@@ -544,6 +570,9 @@ MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w,
             face_pair_hit<1, 2, 0>(lx, hx, ly, hy, lz, hz, rec.prim + 4u, lr.r.o, lr.r.d, lr.rinv, t_min, w.closest, w.best);
             continue;
         }
+        const uint32_t code = rec.code_inst & 0xffu;
+        if ((F & F_RECT) && code >= SC_RECT_XY && code <= SC_RECT_YZ) cost.rect_tests += lanes_here();
+        else cost.sphere_tests += lanes_here();
         float t;
         if (leaf_rec_hit<F>(s, rec, lr, t_min, w.closest, t)) {
             w.closest = t;
@@ -560,6 +589,7 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
     w.next = 0;
     w.ref = kWalkIdle;
     LRay lr;
+    WalkCost cost{0u, 0u, 0u};  // not reported by the callers of whole walks
     while (w.next < n) {
         walk_begin<F>(s, r, w, lr);
         // Two nested loops rather than one step of either kind per iteration: the lanes of a wave
@@ -567,7 +597,7 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
         // intersect their leaves together, so the long leaf code runs with many lanes active.
         while (w.ref != kWalkIdle) {
             while (ref_is_node(w.ref)) walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride);
-            if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, lr, w, stack, stride);
+            if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, lr, w, stack, stride, cost);
         }
     }
 }
@@ -585,8 +615,9 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
 // `steps` receives the number of steps taken (statistics builds read it; otherwise it folds away).
 template <uint32_t F>
 MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t min_lanes,
-                        uint32_t node_lanes, uint32_t* stack, uint32_t stride, uint32_t& steps) {
+                        uint32_t node_lanes, uint32_t* stack, uint32_t stride, uint32_t& steps, uint32_t* wave_cost) {
     steps = 0;
+    WalkCost cost{0u, 0u, 0u};
     LRay lr = make_lray(r);
     if (w.ref != kWalkIdle) lr = walk_ray<F>(s, r, w.next - 1u);  // resuming inside hierarchy w.next - 1
     for (;;) {
@@ -595,10 +626,11 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
             while (ref_is_node(w.ref) && steps < budget) {
                 walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride);
                 ++steps;
+                cost.node_steps += lanes_here();
                 if ((uint32_t)__popcll(__ballot(ref_is_node(w.ref))) < node_lanes) break;
             }
             if (ref_is_leaf(w.ref)) {
-                walk_leaf<F>(s, t_min, lr, w, stack, stride);
+                walk_leaf<F>(s, t_min, lr, w, stack, stride, cost);
                 ++steps;
             }
             // few lanes left walking: they stop here too and go on next iteration, together with the walks
@@ -606,6 +638,11 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
             if ((uint32_t)__popcll(__ballot(w.ref != kWalkIdle)) < min_lanes) budget = steps;
         }
         if (w.ref != kWalkIdle || w.next >= n) break;  // out of budget, or every hierarchy walked
+    }
+    if ((threadIdx.x & 63u) == 0u) {  // the words belong to this wave alone: plain read-modify-write
+        wave_cost[0] += cost.node_steps;
+        wave_cost[1] += cost.sphere_tests;
+        wave_cost[2] += cost.rect_tests;
     }
     return w.ref == kWalkIdle;
 }

@@ -94,6 +94,11 @@ struct __attribute__((aligned(16))) DevPerlin {
     uint8_t perm[3][256];
 };
 
+// Entries of the per-lane traversal stack (LDS, [level][lane]). A walk pushes at most one reference per interior
+// node on its way down, so a hierarchy whose deepest leaf sits at level d (root = level 1) needs d - 1 entries;
+// the upload code builds with this bound and refuses a tree that exceeds it.
+constexpr int kBvhStackDepth = 32;
+
 enum : uint32_t { EK_LIST = 0, EK_BVH = 1 };
 struct __attribute__((aligned(16))) DevEntry {
     uint32_t kind;
@@ -154,6 +159,15 @@ struct DevScene {
     uint32_t n_instances, n_textures;
     uint32_t features;
     float background[3];
+    // Device-side diagnostics. `fault` points at one word the kernels OR bits into when they meet a state the host
+    // promised could not occur (FAULT_*); the host reads it back with the statistics and in the blocking resolve.
+    // stack_limit = entries of the per-lane traversal stack a walk may use (kBvhStackDepth unless a test lowers it).
+    uint32_t* fault;
+    uint32_t stack_limit;
+};
+enum : uint32_t {
+    FAULT_STACK_OVERFLOW = 1u,  // a walk had to push with its stack full: the far child was dropped
+    FAULT_STALE_CHUNK = 2u,     // a (pixel, chunk) slot did not carry the stamp of its launch: its item was never stored
 };
 
 }  // namespace mirt

@@ -1,4 +1,5 @@
 // C entry points of the host-side scene / camera / renderer mirror (include/mirt_host.h).
+#include <memory>
 #include <string>
 #include "../../../include/mirt_host.h"
 #include "png_writer.hpp"
@@ -29,13 +30,16 @@ int mirt_host_select_scene(const char* name, uint32_t scene_seed, int random_num
     if (!name || !out) { g_host_err = "mirt_host_select_scene: NULL argument"; return MIRT_ERR_INVALID; }
     try {
         rt::Scene sc = rt::select_scene(name, options(scene_seed, random_num, earth_rgba, ew, eh));
-        auto* h = new mirt_host_scene();
+        auto h = std::make_unique<mirt_host_scene>();
         h->flat = sc.flatten();
         h->desc = h->flat.desc();
-        *out = h;
+        *out = h.release();
         return MIRT_OK;
     } catch (const std::exception& e) {
         g_host_err = e.what();
+        return MIRT_ERR_INVALID;
+    } catch (...) {
+        g_host_err = "mirt_host_select_scene: unknown exception";
         return MIRT_ERR_INVALID;
     }
 }
@@ -44,8 +48,16 @@ void mirt_host_scene_free(mirt_host_scene* s) { delete s; }
 
 int mirt_host_select_camera(float aspect_ratio, const char* scene, mirt_camera* out) {
     if (!scene || !out) { g_host_err = "mirt_host_select_camera: NULL argument"; return MIRT_ERR_INVALID; }
-    *out = rt::Camera::select_camera(aspect_ratio, scene).c;
-    return MIRT_OK;
+    try {
+        *out = rt::Camera::select_camera(aspect_ratio, scene).c;
+        return MIRT_OK;
+    } catch (const std::exception& e) {
+        g_host_err = e.what();
+        return MIRT_ERR_INVALID;
+    } catch (...) {
+        g_host_err = "mirt_host_select_camera: unknown exception";
+        return MIRT_ERR_INVALID;
+    }
 }
 
 int mirt_host_draw(int device, const char* name, uint32_t width, uint32_t height, uint32_t multisample, uint32_t max_depth,
@@ -64,6 +76,9 @@ int mirt_host_draw(int device, const char* name, uint32_t width, uint32_t height
     } catch (const std::exception& e) {
         g_host_err = e.what();
         return MIRT_ERR_INVALID;
+    } catch (...) {
+        g_host_err = "mirt_host_draw: unknown exception";
+        return MIRT_ERR_INVALID;
     }
 }
 
@@ -74,6 +89,9 @@ int mirt_host_save_png(const char* path, const uint8_t* rgba, uint32_t width, ui
         return MIRT_OK;
     } catch (const std::exception& e) {
         g_host_err = e.what();
+        return MIRT_ERR_INVALID;
+    } catch (...) {
+        g_host_err = "mirt_host_save_png: unknown exception";
         return MIRT_ERR_INVALID;
     }
 }

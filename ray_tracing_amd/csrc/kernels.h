@@ -25,6 +25,11 @@ struct RenderArgs {
     // accum in chunk order by a second kernel.
     uint32_t n_chunks, chunk_spp;
     float4* partial;
+    // Every slot of `partial` a launch fills carries this launch's stamp in its fourth word; the pass that adds the
+    // slots up counts a chunk's samples only when the stamp is there, so an item that was never stored shows as a
+    // short sample count (and FAULT_STALE_CHUNK) instead of passing off an earlier launch's sums. Never 0.
+    uint32_t stamp;
+    uint32_t debug_drop_pixel;  // tests: the item of this pixel's first chunk is not stored (0xffffffff: none)
 };
 enum : uint32_t { LOOP_AUTO = 0, LOOP_FUSED = 1, LOOP_QUEUE = 2 };
 constexpr size_t kWorkCounterBytes = 8 * 128;  // eight counters, one per 128-byte line

@@ -324,6 +324,9 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     Ray ray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f), 0.f};
     V3 thr = v3(1.f, 1.f, 1.f);
     uint32_t segments = 0, rounds = 0;  // of the whole wave (scalar registers)
+    __shared__ uint32_t s_walk_cost[(FT & F_BVH) ? (kBlock / 64) * 3 : 1];  // per wave: node steps, leaf spheres, leaf rects
+    uint32_t* const wave_cost = s_walk_cost + ((FT & F_BVH) ? (threadIdx.x >> 6) * 3u : 0u);
+    if ((FT & F_BVH) && (threadIdx.x & 63u) == 0u) wave_cost[0] = wave_cost[1] = wave_cost[2] = 0u;
     MIRT_STATS(const long long t_birth = clock64(); long long ph0 = 0, ph1 = 0, ph2 = 0);
     Walk wk;               // the lane's walk of the hierarchies, kept from iteration to iteration
     bool walking = false;  // ... which is not over yet
@@ -366,14 +369,16 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     // straight to the accumulation buffer; otherwise to the item's own slot, and reduce_chunks_kernel adds
     // the slots of a pixel in chunk order — no floating-point atomics, so the result does not depend on
     // which lane rendered what, or when.
-    auto flush_pixel = [&pixel, &sample_end, &acc, accum, partial, spp_count, n_chunks, n_pixels, spp_begin, chunk_spp]() {
+    const uint32_t stamp = a.stamp, drop_pixel = a.debug_drop_pixel;
+    auto flush_pixel = [&pixel, &sample_end, &acc, accum, partial, spp_count, n_chunks, n_pixels, spp_begin, chunk_spp, stamp, drop_pixel]() {
+        const uint32_t chunk = (sample_end - 1u - spp_begin) / chunk_spp;
+        if (pixel == drop_pixel && chunk == 0u) return;
         if (n_chunks == 1u) {
             float4 v = accum[pixel];
             v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += spp_count;
             accum[pixel] = v;
         } else {
-            const uint32_t chunk = (sample_end - 1u - spp_begin) / chunk_spp;
-            partial[chunk * n_pixels + pixel] = make_float4(acc.x, acc.y, acc.z, 0.f);
+            partial[chunk * n_pixels + pixel] = make_float4(acc.x, acc.y, acc.z, __uint_as_float(stamp));
         }
     };
 
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
             const uint32_t live = (uint32_t)__popcll(__ballot(alive));
             if (alive && !closed)
                 walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, (walk_min_lanes * live) >> 6,
-                                         (walk_node_lanes * live) >> 6, stack, kBlock, wsteps);
+                                         (walk_node_lanes * live) >> 6, stack, kBlock, wsteps, wave_cost);
             MIRT_STATS(tc2 = clock64());
             MIRT_STATS(walk_histogram(alive, wsteps));
             ready = alive && !walking;
@@ -485,6 +490,11 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     if ((threadIdx.x & 63u) == 0 && a.segment_counter) {
         atomicAdd(a.segment_counter, (unsigned long long)segments);
         atomicAdd(a.segment_counter + 1, 64ull * rounds);
+        if constexpr ((FT & F_BVH) != 0) {
+            atomicAdd(a.segment_counter + 2, (unsigned long long)wave_cost[0]);
+            atomicAdd(a.segment_counter + 3, (unsigned long long)wave_cost[1]);
+            atomicAdd(a.segment_counter + 4, (unsigned long long)wave_cost[2]);
+        }
     }
 }
 
@@ -496,15 +506,23 @@ __global__ __launch_bounds__(kBlock) void count_samples_kernel(float4* accum, ui
 
 // Second step of a persistent launch that split every pixel's samples into chunks: the chunk sums of a
 // pixel, in chunk order, onto the accumulation buffer.
-__global__ __launch_bounds__(kBlock) void reduce_chunks_kernel(float4* accum, const float4* partial, uint32_t n, uint32_t n_chunks, float spp) {
+// A slot counts only when it carries the launch's stamp (RenderArgs::stamp): the sample count of the pixel then
+// grows by the chunk's samples; a slot without it was never stored by this launch and is reported.
+__global__ __launch_bounds__(kBlock) void reduce_chunks_kernel(float4* accum, const float4* partial, uint32_t n, uint32_t n_chunks,
+                                                               uint32_t chunk_spp, uint32_t spp_count, uint32_t stamp, uint32_t* fault) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 v = accum[i];
+    uint32_t counted = 0;
     for (uint32_t c = 0; c < n_chunks; ++c) {
         const float4 p = partial[(size_t)c * n + i];
-        v.x += p.x; v.y += p.y; v.z += p.z;
+        if (__float_as_uint(p.w) == stamp) {
+            v.x += p.x; v.y += p.y; v.z += p.z;
+            counted += min(chunk_spp, spp_count - c * chunk_spp);
+        }
     }
-    v.w += spp;
+    if (counted != spp_count) atomicOr(fault, (uint32_t)FAULT_STALE_CHUNK);
+    v.w += (float)counted;
     accum[i] = v;
 }
 
@@ -630,7 +648,7 @@ static hipError_t launch_persistent(Kernel kernel, const RenderArgs& a, hipStrea
     if ((e = hipGetLastError()) != hipSuccess || a.n_chunks == 1) return e;
     const uint32_t n = a.width * a.height;
     hipLaunchKernelGGL(reduce_chunks_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a.accum, a.partial, n, a.n_chunks,
-                       (float)a.spp_count);
+                       a.chunk_spp, a.spp_count, a.stamp, a.scene.fault);
     return hipGetLastError();
 }
 
@@ -696,7 +714,11 @@ bool render_uses_queue(const RenderArgs& a) {
     static const int env = [] { const char* e = std::getenv("MIRT_QUEUE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     if (!a.work_counter || a.loop == LOOP_FUSED) return false;
     if (a.loop == LOOP_QUEUE) return true;
-    return env >= 0 ? env == 1 : true;
+    if (env >= 0) return env == 1;
+    // A lone primitive without lights (one textured sphere: 1.3 segments per sample, every pixel costs the same)
+    // leaves the item queue nothing to even out, and the trips to its counters are then the larger cost
+    // (measured at 1080p: 62 Gsamples/s with one pixel per lane, 46 through the queue).
+    return !(a.scene.n_prims <= 1u && a.scene.n_lights == 0u);
 }
 hipError_t launch_render_fused(const RenderArgs& a, hipStream_t stream) {
     if (a.width == 0 || a.height == 0 || a.spp_count == 0) return hipSuccess;

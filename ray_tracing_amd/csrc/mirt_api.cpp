@@ -13,39 +13,10 @@
 #include "bvh_build.h"
 #include "dev_types.h"
 #include "kernels.h"
+#include "mirt_ctx.h"
 #include "wavefront.h"
 
 using namespace mirt;
-
-constexpr int kCounters = 2;
-
-struct mirt_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::string err;
-    std::vector<void*> scene_allocs;
-    DevScene scene{};
-    DevCamera cam{};
-    bool has_scene = false, has_camera = false;
-    float4* accum = nullptr;
-    float4* accum_owned = nullptr;
-    size_t accum_owned_pixels = 0;
-    uint32_t width = 0, height = 0;
-    uint8_t* frame_dev = nullptr;
-    size_t frame_dev_bytes = 0;
-    uint32_t n_bvh_nodes = 0;                   // nodes of all hierarchies of the scene
-    uint32_t n_scan_records = 0;                // list-scan records of all list entries
-    float4* partial = nullptr;                  // chunk sums of the persistent kernel (grown on demand)
-    size_t partial_bytes = 0;
-    unsigned long long* seg_counter = nullptr;  // kCounters device counters: segments, lane slots
-    mirt_stats stats{};
-    // wavefront kernel set: path state + queues for `wf_capacity` slots, counters mirrored in pinned memory
-    WfState wf{};
-    uint32_t wf_capacity = 0;
-    std::vector<void*> wf_allocs;
-    uint32_t* wf_counts_host = nullptr;
-};
 
 namespace {
 thread_local std::string g_create_err;
@@ -54,11 +25,35 @@ int fail(mirt_ctx* c, int code, const std::string& msg) {
     if (c) c->err = msg; else g_create_err = msg;
     return code;
 }
+// Runs the body of an entry point; an exception (std::bad_alloc from a scene table, std::system_error from a
+// builder thread) ends at the boundary as an error code, as include/mirt.h promises.
+template <class Body>
+int guarded(mirt_ctx* c, const char* where, Body&& body) {
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        return fail(c, MIRT_ERR_INVALID, std::string(where) + ": " + e.what());
+    } catch (...) {
+        return fail(c, MIRT_ERR_INVALID, std::string(where) + ": unknown exception");
+    }
+}
+}  // namespace
+int mirt::ctx_fail(mirt_ctx* c, int code, const std::string& msg) { return fail(c, code, msg); }
+namespace {
 #define HIP_TRY(ctx, expr)                                                                         \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return fail((ctx), MIRT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+std::string fault_text(uint32_t faults) {
+    std::string m = "the render kernels reported";
+    if (faults & FAULT_STACK_OVERFLOW) m += " [a hierarchy walk overflowed its traversal stack: hits may be missing]";
+    if (faults & FAULT_STALE_CHUNK) m += " [a (pixel, sample chunk) item was never stored: sample counts are short]";
+    return m;
+}
+uint32_t* fault_word(mirt_ctx* c) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->seg_counter) + kFaultOffset); }
+uint32_t* work_counters(mirt_ctx* c) { return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->seg_counter) + kWorkCounterOffset); }
 
 void free_scene(mirt_ctx* c) {
     for (void* p : c->scene_allocs) (void)hipFree(p);
@@ -172,8 +167,9 @@ int mirt_create(int device, mirt_ctx** out) {
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
     // kCounters statistics words, then (from byte 128) the item counters of the persistent render kernel
-    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), kCounters * sizeof(unsigned long long) + 128 + kWorkCounterBytes)) != hipSuccess) return bail("hipMalloc", e);
-    if ((e = hipMemset(c->seg_counter, 0, kCounters * sizeof(unsigned long long) + 128 + kWorkCounterBytes)) != hipSuccess) return bail("hipMemset", e);
+    static_assert(kCounters * sizeof(unsigned long long) <= kFaultOffset && kFaultOffset + 4 <= kWorkCounterOffset, "block layout");
+    if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), kWorkCounterOffset + kWorkCounterBytes)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemset(c->seg_counter, 0, kWorkCounterOffset + kWorkCounterBytes)) != hipSuccess) return bail("hipMemset", e);
     *out = c;
     return MIRT_OK;
 }
@@ -182,6 +178,7 @@ void mirt_destroy(mirt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    comm_release(c);
     free_scene(c);
     if (c->accum_owned) (void)hipFree(c->accum_owned);
     if (c->frame_dev) (void)hipFree(c->frame_dev);
@@ -195,9 +192,14 @@ void mirt_destroy(mirt_ctx* c) {
     delete c;
 }
 
+static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d);
 int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     if (!c) return MIRT_ERR_INVALID;
     if (!d) return fail(c, MIRT_ERR_INVALID, "mirt_scene_upload: desc is NULL");
+    return guarded(c, "mirt_scene_upload", [&] { return scene_upload_impl(c, d); });
+}
+
+static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     auto bad = [&](const std::string& m) { return fail(c, MIRT_ERR_INVALID, "mirt_scene_upload: " + m); };
     if (d->n_prims && !d->prims) return bad("prims is NULL");
     if (d->n_world && !d->world) return bad("world is NULL");
@@ -407,6 +409,7 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     std::vector<DevBvhNode> nodes;
     std::vector<uint32_t> slots;          // first primitive of every leaf record, in tree order
     std::vector<uint8_t> slot_is_cuboid;  // the record stands for the six rects of a cuboid
+    int deepest_leaf = 0;
     for (uint32_t e = 0; e < d->n_world; ++e) {
         const mirt_entry& w = d->world[e];
         DevEntry q{};
@@ -471,8 +474,13 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
             float reach = 0.f;
             for (const BuildObject& o : objs)
                 for (int a = 0; a < 3; ++a) reach = std::max(reach, std::max(std::fabs(o.lo[a]), std::fabs(o.hi[a])));
-            BvhBuilder builder(nodes, slots, 32, records_per_object, std::isfinite(reach) ? reach * 4.76837158e-7f : 0.f);
+            BvhBuilder builder(nodes, slots, kBvhStackDepth, records_per_object, std::isfinite(reach) ? reach * 4.76837158e-7f : 0.f);
             q.bvh_root = builder.build(objs);
+            // a walk pushes at most once per interior level: leaves at level L need L - 1 stack entries
+            deepest_leaf = std::max(deepest_leaf, builder.deepest_leaf());
+            if (builder.deepest_leaf() - 1 > kBvhStackDepth)
+                return bad("entry " + std::to_string(e) + ": hierarchy is " + std::to_string(builder.deepest_leaf()) +
+                           " levels deep, the traversal stack holds " + std::to_string(kBvhStackDepth));
             slot_is_cuboid.resize(slots.size(), cuboids ? 1 : 0);  // marks the slots this entry added
             // the hit record of a BVH member is rebuilt with the entry's transform
             for (uint32_t k = 0; k < w.prim_count; ++k) prims[w.first_prim + k].instance = w.instance;
@@ -552,6 +560,29 @@ int mirt_scene_upload(mirt_ctx* c, const mirt_scene_desc* d) {
     s.n_textures = d->n_textures;
     s.features = features;
     for (int a = 0; a < 3; ++a) s.background[a] = d->background[a];
+    s.fault = fault_word(c);
+    s.stack_limit = (uint32_t)kBvhStackDepth;
+    // (tests lower the limit to see the overflow report of walk_node)
+    if (const char* e = std::getenv("MIRT_DEBUG_STACK_LIMIT")) s.stack_limit = (uint32_t)std::min<long>(std::max<long>(std::atol(e), 0), kBvhStackDepth);
+    c->bvh_deepest_leaf = deepest_leaf;
+    // what one scan of the world's list entries tests (a medium's boundary list is scanned at least once per scan
+    // of the list that holds the medium): the per-segment list term of the algorithmic work
+    c->list_rects = c->list_spheres = c->list_transforms = 0;
+    for (uint32_t e = 0; e < d->n_world; ++e) {
+        if (entries[e].kind != EK_LIST) continue;
+        uint32_t last_inst = 0;
+        auto count_range = [&](uint32_t first, uint32_t count, auto&& self) -> void {
+            for (uint32_t i = first; i < first + count; ++i) {
+                const mirt_prim& p = d->prims[i];
+                if (p.instance && p.instance != last_inst) ++c->list_transforms;
+                last_inst = p.instance;
+                if (p.kind == MIRT_PRIM_RECT) ++c->list_rects;
+                else if (p.kind == MIRT_PRIM_SPHERE) ++c->list_spheres;
+                else self(p.boundary_first, p.boundary_count, self);
+            }
+        };
+        count_range(entries[e].first_prim, entries[e].prim_count, count_range);
+    }
     c->scene = s;
     c->has_scene = true;
     return MIRT_OK;
@@ -594,7 +625,7 @@ int mirt_frame_begin(mirt_ctx* c, uint32_t width, uint32_t height, float* accum_
     c->width = width;
     c->height = height;
     HIP_TRY(c, hipMemsetAsync(c->accum, 0, pixels * sizeof(float4), c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->seg_counter, 0, kCounters * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->seg_counter, 0, kWorkCounterOffset, c->stream));  // statistics and the fault word
     c->stats = mirt_stats{};
     return MIRT_OK;
 }
@@ -684,18 +715,26 @@ int render_wavefront(mirt_ctx* c, const mirt_render_params* p) {
 
 extern "C" {
 
-int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
-    if (!c) return MIRT_ERR_INVALID;
-    if (!p) return fail(c, MIRT_ERR_INVALID, "mirt_render: params is NULL");
-    if (!c->has_scene) return fail(c, MIRT_ERR_STATE, "mirt_render: no scene uploaded");
-    if (!c->has_camera) return fail(c, MIRT_ERR_STATE, "mirt_render: no camera set");
+// Where a render call keeps what it needs beyond inputs and outputs: the item counters of the persistent kernel
+// and the chunk sums. mirt_render uses the context's own block and a buffer it grows on demand; mirt_render_static
+// uses the library's static device array and never allocates.
+struct RenderScratch {
+    uint32_t* work_counter;
+    float4* partial;       // nullptr: take (and grow) the context's buffer
+    size_t partial_bytes;  // capacity behind `partial`
+    bool may_allocate;
+};
+
+static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who, RenderScratch sc) {
+    const std::string w(who);
+    if (!p) return fail(c, MIRT_ERR_INVALID, w + ": params is NULL");
+    if (!c->has_scene) return fail(c, MIRT_ERR_STATE, w + ": no scene uploaded");
+    if (!c->has_camera) return fail(c, MIRT_ERR_STATE, w + ": no camera set");
     if (!c->accum || p->width != c->width || p->height != c->height)
-        return fail(c, MIRT_ERR_STATE, "mirt_render: width/height differ from mirt_frame_begin");
-    if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, "mirt_render: sample range overflows 32 bits");
-    if (p->kernel > MIRT_KERNEL_QUEUE) return fail(c, MIRT_ERR_INVALID, "mirt_render: unknown kernel selector");
+        return fail(c, MIRT_ERR_STATE, w + ": width/height differ from mirt_frame_begin");
+    if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, w + ": sample range overflows 32 bits");
+    if (p->kernel > MIRT_KERNEL_QUEUE) return fail(c, MIRT_ERR_INVALID, w + ": unknown kernel selector");
     HIP_TRY(c, hipSetDevice(c->device));
-    // depth 0 traces nothing (renderer.rs:198-200): the fused kernel just counts the samples
-    if (p->kernel == MIRT_KERNEL_WAVEFRONT && p->max_depth > 0) return render_wavefront(c, p);
     RenderArgs a{};
     a.scene = c->scene;
     a.cam = c->cam;
@@ -703,8 +742,12 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     a.max_depth = p->max_depth; a.seed = p->seed; a.jitter = p->jitter;
     a.accum = c->accum;
     a.segment_counter = c->seg_counter;
-    a.work_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c->seg_counter) + 128);  // own lines, after the statistics words
+    a.work_counter = sc.work_counter;
     a.loop = p->kernel == MIRT_KERNEL_FUSED ? LOOP_FUSED : (p->kernel == MIRT_KERNEL_QUEUE ? LOOP_QUEUE : LOOP_AUTO);
+    // the persistent kernel packs a pixel position into 16 + 16 bits: larger frames go to the one-pixel-per-lane kernel
+    if (p->width > 0xffffu || p->height > 0xffffu) a.loop = LOOP_FUSED;
+    a.debug_drop_pixel = 0xffffffffu;
+    if (const char* e = std::getenv("MIRT_DEBUG_DROP_PIXEL")) a.debug_drop_pixel = (uint32_t)std::atol(e);  // tests of the stale-slot report
     {
         // How the persistent kernel shares a wave between its walks (kernels.h). Measured at 1080p with
         // (lanes walking, lanes descending) out of 64: `random` 1 740 Msamples/s with whole walks, 2 300 with
@@ -738,14 +781,18 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
             // The persistent kernel hands out (pixel, sample chunk) items: with whole pixels as items the launch
             // lasts as long as its most expensive pixel (measured on `final`: the average wave was alive for 46 %
             // of the kernel's duration, the rest was the tail of the pixels on the sphere cluster).
-            a.chunk_spp = (a.spp_count + split - 1) / split;
+            const size_t slot_bytes = (size_t)a.width * a.height * sizeof(float4);
+            uint32_t want = split;
+            // a caller-provided scratch holds a fixed number of chunk images: fewer, longer chunks then
+            if (!sc.may_allocate) want = (uint32_t)std::min<size_t>(want, sc.partial_bytes / slot_bytes);
+            a.chunk_spp = (a.spp_count + want - 1) / std::max(want, 1u);
             a.n_chunks = (a.spp_count + a.chunk_spp - 1) / a.chunk_spp;
             const uint64_t items = (uint64_t)(((a.width + 7u) / 8u) * ((a.height + 7u) / 8u)) * 64u * a.n_chunks;
-            const size_t bytes = (size_t)a.n_chunks * a.width * a.height * sizeof(float4);
-            if (items >= 0xffffff00ull || (uint64_t)a.n_chunks * a.width * a.height >= 0xffffffffull) {
+            const size_t bytes = (size_t)a.n_chunks * slot_bytes;
+            if (want < 2 || items >= 0xffffff00ull || (uint64_t)a.n_chunks * a.width * a.height >= 0xffffffffull) {
                 a.n_chunks = 1;
                 a.chunk_spp = a.spp_count;
-            } else if (a.n_chunks > 1 && bytes > c->partial_bytes) {
+            } else if (sc.may_allocate && a.n_chunks > 1 && bytes > c->partial_bytes) {
                 if (c->partial) HIP_TRY(c, hipFree(c->partial));
                 c->partial = nullptr;
                 c->partial_bytes = 0;
@@ -753,7 +800,10 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
                 c->partial_bytes = bytes;
             }
         }
-        a.partial = c->partial;
+        a.partial = sc.may_allocate ? c->partial : sc.partial;
+        if (++c->stamp == 0) c->stamp = 1;
+        // (a stamp is a float's bit pattern in a slot nobody reads as a float; it only has to differ from launch to launch)
+        a.stamp = c->stamp;
         HIP_TRY(c, hipMemsetAsync(a.work_counter, 0, kWorkCounterBytes, c->stream));
         HIP_TRY(c, launch_render_fused(a, c->stream));
         ++launches;
@@ -765,12 +815,38 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     return MIRT_OK;
 }
 
+int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
+    if (!c) return MIRT_ERR_INVALID;
+    // depth 0 traces nothing (renderer.rs:198-200): the fused kernel just counts the samples
+    if (p && p->kernel == MIRT_KERNEL_WAVEFRONT && p->max_depth > 0) {
+        if (!c->has_scene) return fail(c, MIRT_ERR_STATE, "mirt_render: no scene uploaded");
+        if (!c->has_camera) return fail(c, MIRT_ERR_STATE, "mirt_render: no camera set");
+        if (!c->accum || p->width != c->width || p->height != c->height)
+            return fail(c, MIRT_ERR_STATE, "mirt_render: width/height differ from mirt_frame_begin");
+        if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, "mirt_render: sample range overflows 32 bits");
+        HIP_TRY(c, hipSetDevice(c->device));
+        return render_wavefront(c, p);
+    }
+    return render_impl(c, p, "mirt_render", RenderScratch{work_counters(c), nullptr, 0, true});
+}
+
 int mirt_resolve_rgba8_device(mirt_ctx* c, uint8_t* frame_device, size_t len) {
     if (!c) return MIRT_ERR_INVALID;
     if (!c->accum) return fail(c, MIRT_ERR_STATE, "mirt_resolve_rgba8: no frame begun");
-    if (!frame_device) return fail(c, MIRT_ERR_INVALID, "mirt_resolve_rgba8: frame is NULL");
     if (len != (size_t)c->width * c->height * 4) return fail(c, MIRT_ERR_INVALID, "mirt_resolve_rgba8: len != width*height*4 (renderer.rs:65)");
     HIP_TRY(c, hipSetDevice(c->device));
+    if (!frame_device) {
+        // the library's own device frame (the one the host variant stages through)
+        if (c->frame_dev_bytes < len) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->frame_dev) (void)hipFree(c->frame_dev);
+            c->frame_dev = nullptr;
+            c->frame_dev_bytes = 0;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->frame_dev), len));
+            c->frame_dev_bytes = len;
+        }
+        frame_device = c->frame_dev;
+    }
     HIP_TRY(c, launch_resolve_rgba8(c->accum, frame_device, c->width, c->height, c->stream));
     return MIRT_OK;
 }
@@ -791,7 +867,10 @@ int mirt_resolve_rgba8(mirt_ctx* c, uint8_t* frame, size_t len) {
     }
     HIP_TRY(c, launch_resolve_rgba8(c->accum, c->frame_dev, c->width, c->height, c->stream));
     HIP_TRY(c, hipMemcpyAsync(frame, c->frame_dev, len, hipMemcpyDeviceToHost, c->stream));
+    uint32_t faults = 0;
+    HIP_TRY(c, hipMemcpyAsync(&faults, fault_word(c), sizeof(faults), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (faults) return fail(c, MIRT_ERR_DEVICE, "mirt_resolve_rgba8: " + fault_text(faults));
     return MIRT_OK;
 }
 
@@ -898,8 +977,19 @@ int mirt_get_stats(mirt_ctx* c, mirt_stats* out) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     unsigned long long seg[kCounters] = {};
     HIP_TRY(c, hipMemcpy(seg, c->seg_counter, sizeof(seg), hipMemcpyDeviceToHost));
+    uint32_t faults = 0;
+    HIP_TRY(c, hipMemcpy(&faults, fault_word(c), sizeof(faults), hipMemcpyDeviceToHost));
     c->stats.segments = seg[0];
     c->stats.lane_slots = seg[1];
+    c->stats.bvh_node_steps = seg[2];
+    c->stats.bvh_sphere_tests = seg[3];
+    c->stats.bvh_rect_tests = seg[4];
+    c->stats.list_rects = c->list_rects;
+    c->stats.list_spheres = c->list_spheres;
+    c->stats.list_transforms = c->list_transforms;
+    c->stats.device_faults = faults;
+    c->stats.bvh_deepest_leaf = (uint32_t)c->bvh_deepest_leaf;
+    if (faults) c->err = fault_text(faults);
     if (c->stats.kernel_launches) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.kernel_ms = ms;

@@ -1,7 +1,9 @@
 """Multi-GPU split of the sample loop: one process per GPU, each renders a contiguous range of the
-samples of every pixel; the float4 accumulation buffers are summed with one collective (RCCL when the
-process group's backend is "nccl"). The Philox key holds the GLOBAL sample index, so the ranks' streams
-are disjoint and the reduced image equals a single-GPU render of all samples up to fp32 reassociation."""
+samples of every pixel; the float4 accumulation buffers are summed onto one rank by the library's own RCCL
+reduce (mirt_comm_reduce, on the render stream). torch.distributed is the control plane only: it carries the
+128-byte communicator id from rank 0 to the others and provides the barriers; its backend can be gloo.
+The Philox key holds the GLOBAL sample index, so the ranks' streams are disjoint and the reduced image
+equals a single-GPU render of all samples up to fp32 reassociation."""
 
 
 def sample_range(total_spp, world_size, rank):
@@ -25,3 +27,14 @@ def reduce_accum(accum, dst=0, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
     return accum
+
+
+def join_comm(ctx, rank, world_size, group=None):
+    """Make `ctx` rank `rank` of an RCCL communicator of `world_size` contexts, one per process: rank 0 creates
+    the id, the process group broadcasts its bytes, every rank joins (collective: all ranks must call it)."""
+    import torch.distributed as dist
+    import ray_tracing_amd as rt
+    ids = [rt.comm_unique_id() if rank == 0 else None]
+    if world_size > 1:
+        dist.broadcast_object_list(ids, src=0, group=group)
+    ctx.comm_init_rank(world_size, rank, ids[0])

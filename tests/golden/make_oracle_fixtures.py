@@ -1,5 +1,5 @@
 """Generates the oracle-made golden vectors under tests/golden/ (run from the repository root:
-`python tests/golden/make_oracle_fixtures.py`). The reference ships no fixtures and cannot be built in
+`python tests/golden/make_oracle_fixtures.py`; `... converged final` remakes one converged image only). The reference ships no fixtures and cannot be built in
 this environment, so these vectors come from the CPU oracle (oracle/), which is itself pinned only by
 the analytic Cornell known answers, the Philox known answers and the sampler properties — they freeze the
 oracle's behaviour so that a later change of the oracle or of the device code shows up against fixed
@@ -23,7 +23,7 @@ import oracle as O  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
 SCENES = ["cornell", "smoke", "random", "final", "2sp", "2psp", "earth", "simplelight"]
-CONVERGED = {"cornell": 16384, "smoke": 8192, "random": 4096, "final": 2048}
+CONVERGED = {"cornell": 16384, "smoke": 8192, "random": 4096, "final": 4096}
 FW, FH = 64, 36
 CW, CH = 96, 54
 
@@ -36,7 +36,8 @@ def earth():
 
 def main():
     e = earth()
-    for name in SCENES:
+    only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "converged" else None
+    for name in ([] if only else SCENES):
         orc = O.OracleRenderer(name, FW, FH, earth_rgba=e if name in ("earth", "final") else None)
         ids, t = orc.first_hit(orc.camera_rays(0.5), seed=11)
         assert ids.max() < 32767
@@ -44,6 +45,8 @@ def main():
                             t=t.reshape(FH, FW))
         print(name, "first hits:", int((ids >= 0).sum()), "of", ids.size, flush=True)
     for name, spp in CONVERGED.items():
+        if only and name not in only:
+            continue
         t0 = time.time()
         orc = O.OracleRenderer(name, CW, CH, earth_rgba=e if name == "final" else None)
         a, _ = orc.render_sums(spp // 2, 50, seed=1000, spp_begin=0)

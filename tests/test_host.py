@@ -33,6 +33,8 @@ def test_struct_sizes_match_header(rt):
     assert ctypes.sizeof(rt.mirt_material) == 24
     assert ctypes.sizeof(rt.mirt_texture) == 40
     assert ctypes.sizeof(rt.mirt_perlin) == 256 * 12 + 768
+    assert ctypes.sizeof(rt.mirt_stats) == 3 * 8 + 2 * 4 + 8 + 3 * 8 + 5 * 4 + 4      # 4 bytes of tail padding
+    assert rt.mirt_stats.device_faults.offset == 76
 
 
 def test_host_philox_matches_oracle(rt, oracle):
