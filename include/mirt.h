@@ -201,6 +201,19 @@ int mirt_frame_begin(mirt_ctx* ctx, uint32_t width, uint32_t height, float* accu
  * multi-GPU split the same call. */
 int mirt_render(mirt_ctx* ctx, const mirt_render_params* p);
 
+/* mirt_render for callers that cannot allocate device memory — code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc. It has no counterpart in the reference. It renders the same samples with the
+ * persistent kernel (kernel = MIRT_KERNEL_AUTO or MIRT_KERNEL_QUEUE), but the kernel's item counters and chunk sums
+ * live in a static device array of the library (256 MiB + 4 KiB, held on every GPU the library runs on until the
+ * process ends) instead of buffers grown on demand, and the call allocates and frees nothing. Frames of more than
+ * MIRT_STATIC_MAX_PIXELS pixels (two chunk images must fit) or 65535 in one dimension are rejected. A frame that
+ * fits sixteen chunk images (up to 1 Mi pixels) gets the sums of mirt_render bit for bit; a larger one gets fewer,
+ * longer chunks, i.e. another grouping of the same float additions. All calls on one GPU share that GPU's array:
+ * calls that overlap on one GPU (two contexts, two streams) race; one at a time is the contract. The frame
+ * (mirt_frame_begin, itself allocation-free with a caller-owned accum_device), scene and camera are set up before. */
+#define MIRT_STATIC_MAX_PIXELS 8388608u
+int mirt_render_static(mirt_ctx* ctx, const mirt_render_params* p);
+
 /* renderer.rs:109-116 and the row flip of :97: mean, clamp [0,0.999], sqrt, *256, truncate; alpha
  * 0xff; top row first. frame is a HOST buffer of len == width*height*4 bytes (checked, mirrors the
  * assert of renderer.rs:65). Blocks until done. Returns MIRT_ERR_DEVICE (frame still written) when the

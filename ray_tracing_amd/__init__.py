@@ -22,7 +22,7 @@ KERNEL_AUTO, KERNEL_FUSED, KERNEL_WAVEFRONT, KERNEL_QUEUE = 0, 1, 2, 3
 # every symbol include/mirt.h and include/mirt_host.h declare
 EXPORTS = [
     "mirt_create", "mirt_destroy", "mirt_last_error", "mirt_scene_upload", "mirt_camera_set", "mirt_frame_begin",
-    "mirt_render", "mirt_resolve_rgba8", "mirt_resolve_rgba8_device", "mirt_read_accum", "mirt_write_accum",
+    "mirt_render", "mirt_render_static", "mirt_resolve_rgba8", "mirt_resolve_rgba8_device", "mirt_read_accum", "mirt_write_accum",
     "mirt_accum_device_ptr",
     "mirt_first_hit", "mirt_ray_color", "mirt_synchronize", "mirt_get_stats", "mirt_philox4x32_10",
     "mirt_reduce", "mirt_comm_unique_id", "mirt_comm_init_rank", "mirt_comm_reduce", "mirt_comm_ranks",
@@ -129,6 +129,7 @@ def lib():
         L.mirt_camera_set.argtypes = [vp, C.POINTER(mirt_camera)]
         L.mirt_frame_begin.argtypes = [vp, u32, u32, vp]
         L.mirt_render.argtypes = [vp, C.POINTER(mirt_render_params)]
+        L.mirt_render_static.argtypes = [vp, C.POINTER(mirt_render_params)]
         L.mirt_resolve_rgba8.argtypes = [vp, vp, sz]
         L.mirt_resolve_rgba8_device.argtypes = [vp, vp, sz]
         L.mirt_read_accum.argtypes = [vp, vp, sz]
@@ -282,6 +283,11 @@ class Context:
     def render(self, spp_count, max_depth, spp_begin=0, seed=0, jitter=True, kernel=KERNEL_AUTO):
         p = mirt_render_params(self.width, self.height, spp_begin, spp_count, max_depth, seed, 1 if jitter else 0, kernel)
         self._check(lib().mirt_render(self._c, C.byref(p)))
+
+    def render_static(self, spp_count, max_depth, spp_begin=0, seed=0, jitter=True, kernel=KERNEL_AUTO):
+        """mirt_render_static: the same samples without any device allocation (static scratch, bounded frame size)."""
+        p = mirt_render_params(self.width, self.height, spp_begin, spp_count, max_depth, seed, 1 if jitter else 0, kernel)
+        self._check(lib().mirt_render_static(self._c, C.byref(p)))
 
     def resolve_rgba8(self, frame=None):
         if frame is None:

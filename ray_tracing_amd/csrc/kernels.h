@@ -36,6 +36,14 @@ constexpr size_t kWorkCounterBytes = 8 * 128;  // eight counters, one per 128-by
 // Whether launch_render_fused() renders these arguments with the persistent pixel-queue kernel.
 bool render_uses_queue(const RenderArgs& a);
 
+// The library's static scratch: a file-scope device array (kernels.hip) that mirt_render_static renders from instead of
+// allocated buffers — item counters in its first kWorkCounterBytes, chunk sums from kStaticPartialOffset on. Every
+// device the library runs on holds its own copy at its own address; static_scratch_address() returns the copy of the
+// CURRENT device (looked up once per device with hipGetSymbolAddress and kept).
+constexpr size_t kStaticPartialOffset = 4096;
+constexpr size_t kStaticPartialBytes = 256u << 20;  // two chunk images of 8 Mi pixels, or eight of a 1920x1080 frame
+hipError_t static_scratch_address(void** out);
+
 struct RayBatchArgs {
     DevScene scene;
     const float* rays;  // n x 7: origin, direction, time

@@ -14,6 +14,7 @@
 //   resolve_kernel       mean, clamp, sqrt, *256 -> RGBA8 with the row flip (renderer.rs:97,109-116).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include "kernels.h"
 #include "dev_core.h"
 
@@ -709,6 +710,29 @@ extern "C" void mirt_debug_walk_hist(unsigned long long* out) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof(g_phase));
 }
 #endif
+// The static scratch of mirt_render_static (kernels.h). In host code the array's name only stands for the symbol: the
+// memory is reached through the per-device address below, never through the name.
+static __device__ __align__(256) unsigned char scratch[kStaticPartialOffset + kStaticPartialBytes];
+
+hipError_t static_scratch_address(void** out) {
+    constexpr int kMaxDevices = 64;
+    static std::mutex mu;
+    static void* per_device[kMaxDevices] = {};
+    *out = nullptr;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!per_device[device]) {
+        void* p = nullptr;
+        if ((e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch))) != hipSuccess) return e;
+        per_device[device] = p;
+    }
+    *out = per_device[device];
+    return hipSuccess;
+}
+
 bool render_uses_queue(const RenderArgs& a) {
     // the environment variable overrides an AUTO choice for A/B runs of whole programs
     static const int env = [] { const char* e = std::getenv("MIRT_QUEUE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();

@@ -170,6 +170,8 @@ int mirt_create(int device, mirt_ctx** out) {
     static_assert(kCounters * sizeof(unsigned long long) <= kFaultOffset && kFaultOffset + 4 <= kWorkCounterOffset, "block layout");
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), kWorkCounterOffset + kWorkCounterBytes)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->seg_counter, 0, kWorkCounterOffset + kWorkCounterBytes)) != hipSuccess) return bail("hipMemset", e);
+    // this device's copy of the static scratch array (mirt_render_static renders without allocating)
+    if ((e = static_scratch_address(&c->static_scratch)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
     *out = c;
     return MIRT_OK;
 }
@@ -828,6 +830,20 @@ int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
         return render_wavefront(c, p);
     }
     return render_impl(c, p, "mirt_render", RenderScratch{work_counters(c), nullptr, 0, true});
+}
+
+int mirt_render_static(mirt_ctx* c, const mirt_render_params* p) {
+    if (!c) return MIRT_ERR_INVALID;
+    if (!p) return fail(c, MIRT_ERR_INVALID, "mirt_render_static: params is NULL");
+    if (p->kernel != MIRT_KERNEL_AUTO && p->kernel != MIRT_KERNEL_QUEUE)
+        return fail(c, MIRT_ERR_INVALID, "mirt_render_static: only the persistent kernel (MIRT_KERNEL_AUTO / MIRT_KERNEL_QUEUE) renders from the static scratch");
+    if (p->width > 0xffffu || p->height > 0xffffu || (uint64_t)p->width * p->height > MIRT_STATIC_MAX_PIXELS)
+        return fail(c, MIRT_ERR_INVALID, "mirt_render_static: frame exceeds MIRT_STATIC_MAX_PIXELS (" + std::to_string(MIRT_STATIC_MAX_PIXELS) +
+                                             " pixels, two chunk images in the static scratch) or 65535 in one dimension");
+    if (!c->static_scratch) return fail(c, MIRT_ERR_STATE, "mirt_render_static: no static scratch on this device");
+    char* base = static_cast<char*>(c->static_scratch);
+    return render_impl(c, p, "mirt_render_static",
+                       RenderScratch{reinterpret_cast<uint32_t*>(base), reinterpret_cast<float4*>(base + kStaticPartialOffset), kStaticPartialBytes, false});
 }
 
 int mirt_resolve_rgba8_device(mirt_ctx* c, uint8_t* frame_device, size_t len) {

@@ -39,6 +39,7 @@ struct mirt_ctx {
     size_t partial_bytes = 0;
     unsigned long long* seg_counter = nullptr;  // the device block described above
     uint32_t stamp = 0;                         // stamp of the last persistent launch (RenderArgs::stamp)
+    void* static_scratch = nullptr;             // this device's copy of the library's static scratch array
     mirt_stats stats{};
     // wavefront kernel set: path state + queues for `wf_capacity` slots, counters mirrored in pinned memory
     mirt::WfState wf{};
