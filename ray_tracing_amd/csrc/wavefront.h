@@ -1,42 +1,45 @@
-// Launch interface of the wavefront kernel set (wavefront.hip): path state in device memory, one slot
-// per pixel, queues of slot indices between the stages.
+// Launch interface of the wavefront kernel set (wavefront.hip): the sample loop as rounds of small kernels over a
+// pool of path slots in device memory, driven from the device — the host enqueues rounds without reading anything
+// back and only looks at the live count once per batch of rounds.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
+#include "kernels.h"
 
 namespace mirt {
 
-constexpr uint32_t WF_KINDS = 5;  // MK_LAMBERTIAN .. MK_ISOTROPIC
-// counters (uint32 each)
-enum : uint32_t { WF_N_NEW = 0, WF_N_CUR = 1, WF_N_NEXT = 2, WF_N_MAT = 3, WF_N_COUNTS = WF_N_MAT + WF_KINDS };
-
+// One path per slot, structure of arrays (80 bytes per slot).
 struct WfState {
-    float4* rayo;   // origin.xyz, time
-    float4* rayd;   // direction.xyz, -
-    float4* thr;    // throughput.xyz, -
-    uint4* ids;     // sample, bounce, depth_left, hit primitive
-    float* hit_t;
-    uint32_t* q_new;   // slots that start their next sample
-    uint32_t* q_cur;   // live paths of this iteration
-    uint32_t* q_next;  // paths that scattered and go on
-    uint32_t* q_mat;   // WF_KINDS queues of `capacity` entries: hits by material kind
-    uint32_t* counts;  // WF_N_COUNTS counters
+    float4* rayo;  // origin.xyz, time
+    float4* rayd;  // direction.xyz, t of the closest hit so far
+    float4* thr;   // throughput.xyz, bits of the hit primitive (int, -1 = none)
+    float4* acc;   // sample sums of the slot's work item .xyz, bits of its pixel position x | y << 16
+    uint4* ids;    // pixel, sample, end of the item's sample range, bounce
+    uint32_t* q[2];  // live slots: round r reads q[r & 1] and fills q[(r + 1) & 1]
+    uint32_t* ctl;   // control words, WF_CTL_* (each in its own 128-byte line)
+};
+// control words (indices of 32-bit words; a stride of 32 words keeps the contended ones in separate lines)
+enum : uint32_t {
+    WF_CTL_STRIDE = 32,
+    WF_CTL_N0 = 0 * WF_CTL_STRIDE,      // entries in q[0]
+    WF_CTL_N1 = 1 * WF_CTL_STRIDE,      // entries in q[1]
+    WF_CTL_CURSOR = 2 * WF_CTL_STRIDE,  // fetch position of the walk kernel in this round's queue
+    WF_CTL_ITEM = 3 * WF_CTL_STRIDE,    // next work item to hand out
+    WF_CTL_WORDS = 4 * WF_CTL_STRIDE,
 };
 
 struct WfArgs {
-    DevScene scene;
-    DevCamera cam;
+    RenderArgs r;       // scene, camera, frame, sample range, chunking (n_chunks, chunk_spp, partial, stamp), statistics
     WfState st;
-    float4* accum;
-    unsigned long long* segment_counter;
-    uint32_t width, height, capacity;
-    uint32_t n_new, n_cur;
-    uint32_t sample_end, max_depth, seed, jitter;
+    uint32_t capacity;  // slots in the pool
+    uint32_t round;     // parity selects the queues
+    uint32_t refill_lanes;  // the walk kernel fetches new rays when this many lanes of a wave are idle
 };
 
-hipError_t wf_launch_reset(const WfState& st, uint32_t n, uint32_t spp_begin, hipStream_t stream);
-hipError_t wf_launch_generate(const WfArgs& a, hipStream_t stream);
-hipError_t wf_launch_extend(const WfArgs& a, hipStream_t stream);
-hipError_t wf_launch_shade(const WfArgs& a, hipStream_t stream);
+// Slots 0 .. capacity - 1 take the first work items, get their camera rays and fill q[0].
+hipError_t wf_launch_init(const WfArgs& a, hipStream_t stream);
+// One round: closest hit of every live path (list scan, then the persistent hierarchy walk), then shading /
+// scattering / next sample / next item, which fills the other queue.
+hipError_t wf_launch_round(const WfArgs& a, hipStream_t stream);
 
 }  // namespace mirt
