@@ -170,19 +170,26 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms, launches = 0.0, 0
-    tot = {k: 0 for k in ("segments", "bvh_node_steps", "bvh_sphere_tests", "bvh_rect_tests")}
+    tot = {k: 0 for k in ("segments", "bvh_node_steps", "bvh_sphere_tests", "bvh_rect_tests")}   # bvh_*: filled by the counting pass below
     st = {}
     for _ in range(args.steps):
         step()
         st = ctx.stats()                    # HIP-event time of this step's render launches, on the render stream
         kernel_ms += st["kernel_ms"]
         launches += st["kernel_launches"]
-        for k in tot:
-            tot[k] += st[k]
+        tot["segments"] += st["segments"]
         if st["device_faults"]:
             raise SystemExit(f"device faults {st['device_faults']}")
     barrier()
     elapsed = time.perf_counter() - t0
+    # one more pass, outside the timed region, that also tallies what the hierarchy walks cost (nodes visited, leaf
+    # primitives intersected): the per-segment work the roofline figure is priced with
+    if rank == 0 and st.get("kernel_used") in (rt.KERNEL_QUEUE, rt.KERNEL_WAVEFRONT) and scene.desc.n_prims > 32:
+        ctx.frame_begin(W, H)
+        ctx.render(min(count, 16), depth, spp_begin=begin, seed=0, jitter=jitter, kernel=st["kernel_used"] | rt.KERNEL_COUNT_WALKS)
+        ct = ctx.stats()
+        for k in ("bvh_node_steps", "bvh_sphere_tests", "bvh_rect_tests"):
+            tot[k] = ct[k] * tot["segments"] // max(ct["segments"], 1)      # scaled to the timed steps' segments
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -144,6 +144,10 @@ typedef struct mirt_ray { float origin[3], direction[3], time; } mirt_ray;
  * comparison baseline). AUTO takes QUEUE. All forms render the same samples; QUEUE and FUSED differ only in the
  * grouping of the float additions of a pixel's samples (none when spp_count is 1). */
 enum { MIRT_KERNEL_AUTO = 0, MIRT_KERNEL_FUSED = 1, MIRT_KERNEL_WAVEFRONT = 2, MIRT_KERNEL_QUEUE = 3 };
+/* OR-ed into mirt_render_params.kernel: the persistent kernel and the wavefront walk kernel also tally what their
+ * hierarchy walks cost (mirt_stats.bvh_*). Tallying slows the launch by a few percent: for measurement passes, not
+ * for timed ones. */
+#define MIRT_KERNEL_COUNT_WALKS 0x100u
 
 typedef struct mirt_render_params {
     uint32_t width, height;

@@ -428,16 +428,11 @@ constexpr uint32_t kRefLeafIndexMask = (1u << 27) - 1u;
 MIRT_DEV bool ref_is_leaf(uint32_t ref) { return ref != kWalkIdle && (ref & kRefLeaf); }
 MIRT_DEV bool ref_is_node(uint32_t ref) { return !(ref & kRefLeaf); }
 
-// What the walks of a wave have cost, counted per lane that took the step (wave-uniform sums kept in scalar
-// registers while a walk runs: one s_bcnt1 of the exec mask per step). walk_some() adds them to the wave's three
-// words in LDS when its turn ends, so nothing stays in registers over the shading code; the render kernel adds
-// the words to the statistics block once per wave. Where nobody reads them the counters fold away.
-struct WalkCost {
-    uint32_t node_steps;    // interior nodes visited (two child boxes tested each)
-    uint32_t sphere_tests;  // leaf spheres intersected
-    uint32_t rect_tests;    // leaf rects intersected (six per cuboid record)
-};
-MIRT_DEV uint32_t lanes_here() { return (uint32_t)__popcll(__ballot(true)); }
+// What a lane's walk costs is tallied in one register while walk_some() runs: leaf steps in bits 0-9, leaf spheres
+// intersected in bits 10-20, leaf rects intersected (six per cuboid record) in bits 21-31; with the lane's step count
+// that also gives the interior nodes it visited. Only a launch that was asked to count adds the tallies to the wave's
+// three words in LDS (64 lanes adding to one word is slow enough to keep out of the timed launches).
+constexpr uint32_t kTallyLeafStep = 1u, kTallySphere = 1u << 10, kTallyRect = 1u << 21;
 
 struct Walk {
     uint32_t ref;    // current reference (interior node index or leaf run) or kWalkIdle
@@ -556,12 +551,12 @@ MIRT_DEV bool leaf_rec_hit(const DevScene& s, const DevLeafRec& rec, const LRay&
 
 // The records of one leaf, in object order (a later record wins a tie, as in ray.rs:123-133).
 template <uint32_t F>
-MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w, const uint32_t* stack, uint32_t stride, WalkCost& cost) {
+MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w, const uint32_t* stack, uint32_t stride, uint32_t& tally) {
     const uint32_t first = w.ref & kRefLeafIndexMask, n = ((w.ref >> 27) & 15u) + 1u;
     for (uint32_t j = 0; j < n; ++j) {
         const DevLeafRec& rec = s.bvh_leaves[first + j];
         if ((F & F_RECT) && (rec.code_inst & 0xffu) == SC_CUBOID) {
-            cost.rect_tests += 6u * lanes_here();
+            tally += 6u * kTallyRect;
             // Cuboid (geo.rs:245-289): its six rects in list order — XY at z lo / hi, XZ at y lo / hi, YZ at
             // x lo / hi — from the two corners f = (lo.xyz, hi.xyz); ids prim .. prim + 5
             const float lx = rec.f[0], ly = rec.f[1], lz = rec.f[2], hx = rec.f[3], hy = rec.f[4], hz = rec.f[5];
@@ -571,8 +566,7 @@ MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w,
             continue;
         }
         const uint32_t code = rec.code_inst & 0xffu;
-        if ((F & F_RECT) && code >= SC_RECT_XY && code <= SC_RECT_YZ) cost.rect_tests += lanes_here();
-        else cost.sphere_tests += lanes_here();
+        tally += ((F & F_RECT) && code >= SC_RECT_XY && code <= SC_RECT_YZ) ? kTallyRect : kTallySphere;
         float t;
         if (leaf_rec_hit<F>(s, rec, lr, t_min, w.closest, t)) {
             w.closest = t;
@@ -589,7 +583,7 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
     w.next = 0;
     w.ref = kWalkIdle;
     LRay lr;
-    WalkCost cost{0u, 0u, 0u};  // not reported by the callers of whole walks
+    uint32_t tally = 0;  // not reported by the callers of whole walks
     while (w.next < n) {
         walk_begin<F>(s, r, w, lr);
         // Two nested loops rather than one step of either kind per iteration: the lanes of a wave
@@ -597,7 +591,7 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
         // intersect their leaves together, so the long leaf code runs with many lanes active.
         while (w.ref != kWalkIdle) {
             while (ref_is_node(w.ref)) walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride);
-            if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, lr, w, stack, stride, cost);
+            if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, lr, w, stack, stride, tally);
         }
     }
 }
@@ -617,7 +611,7 @@ template <uint32_t F>
 MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t min_lanes,
                         uint32_t node_lanes, uint32_t* stack, uint32_t stride, uint32_t& steps, uint32_t* wave_cost) {
     steps = 0;
-    WalkCost cost{0u, 0u, 0u};
+    uint32_t tally = 0;
     LRay lr = make_lray(r);
     if (w.ref != kWalkIdle) lr = walk_ray<F>(s, r, w.next - 1u);  // resuming inside hierarchy w.next - 1
     for (;;) {
@@ -626,11 +620,11 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
             while (ref_is_node(w.ref) && steps < budget) {
                 walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride);
                 ++steps;
-                cost.node_steps += lanes_here();
                 if ((uint32_t)__popcll(__ballot(ref_is_node(w.ref))) < node_lanes) break;
             }
             if (ref_is_leaf(w.ref)) {
-                walk_leaf<F>(s, t_min, lr, w, stack, stride, cost);
+                walk_leaf<F>(s, t_min, lr, w, stack, stride, tally);
+                tally += kTallyLeafStep;
                 ++steps;
             }
             // few lanes left walking: they stop here too and go on next iteration, together with the walks
@@ -639,10 +633,10 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
         }
         if (w.ref != kWalkIdle || w.next >= n) break;  // out of budget, or every hierarchy walked
     }
-    if ((threadIdx.x & 63u) == 0u) {  // the words belong to this wave alone: plain read-modify-write
-        wave_cost[0] += cost.node_steps;
-        wave_cost[1] += cost.sphere_tests;
-        wave_cost[2] += cost.rect_tests;
+    if (wave_cost) {  // wave-uniform: a counting launch
+        atomicAdd(wave_cost + 0, steps - (tally & 1023u));
+        atomicAdd(wave_cost + 1, (tally >> 10) & 2047u);
+        atomicAdd(wave_cost + 2, tally >> 21);
     }
     return w.ref == kWalkIdle;
 }

@@ -30,6 +30,7 @@ struct RenderArgs {
     // short sample count (and FAULT_STALE_CHUNK) instead of passing off an earlier launch's sums. Never 0.
     uint32_t stamp;
     uint32_t debug_drop_pixel;  // tests: the item of this pixel's first chunk is not stored (0xffffffff: none)
+    uint32_t count_cost;        // tally the hierarchy walks' node steps and leaf tests into the statistics (slower: not for timed launches)
 };
 enum : uint32_t { LOOP_AUTO = 0, LOOP_FUSED = 1, LOOP_QUEUE = 2 };
 constexpr size_t kWorkCounterBytes = 8 * 128;  // eight counters, one per 128-byte line
@@ -59,6 +60,8 @@ struct RayBatchArgs {
 // ray, then one ray segment per loop iteration (trace + shade) with the path state in registers. With
 // a.n_chunks > 1 the launch is followed by the pass that adds the chunk sums in a.partial to a.accum.
 hipError_t launch_render_fused(const RenderArgs& a, hipStream_t stream);
+// The pass that adds the stamped chunk sums in a.partial to a.accum (after a launch with a.n_chunks > 1).
+hipError_t launch_reduce_chunks(const RenderArgs& a, hipStream_t stream);
 hipError_t launch_first_hit(const RayBatchArgs& a, hipStream_t stream);
 hipError_t launch_ray_color(const RayBatchArgs& a, hipStream_t stream);
 hipError_t launch_resolve_rgba8(const float4* accum, uint8_t* frame, uint32_t width, uint32_t height, hipStream_t stream);

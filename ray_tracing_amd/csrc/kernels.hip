@@ -326,8 +326,9 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     V3 thr = v3(1.f, 1.f, 1.f);
     uint32_t segments = 0, rounds = 0;  // of the whole wave (scalar registers)
     __shared__ uint32_t s_walk_cost[(FT & F_BVH) ? (kBlock / 64) * 3 : 1];  // per wave: node steps, leaf spheres, leaf rects
-    uint32_t* const wave_cost = s_walk_cost + ((FT & F_BVH) ? (threadIdx.x >> 6) * 3u : 0u);
-    if ((FT & F_BVH) && (threadIdx.x & 63u) == 0u) wave_cost[0] = wave_cost[1] = wave_cost[2] = 0u;
+    uint32_t* const wave_words = s_walk_cost + ((FT & F_BVH) ? (threadIdx.x >> 6) * 3u : 0u);
+    if ((FT & F_BVH) && (threadIdx.x & 63u) == 0u) wave_words[0] = wave_words[1] = wave_words[2] = 0u;
+    uint32_t* const wave_cost = a.count_cost ? wave_words : nullptr;  // only a counting launch tallies (walk_some)
     MIRT_STATS(const long long t_birth = clock64(); long long ph0 = 0, ph1 = 0, ph2 = 0);
     Walk wk;               // the lane's walk of the hierarchies, kept from iteration to iteration
     bool walking = false;  // ... which is not over yet
@@ -492,13 +493,16 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         atomicAdd(a.segment_counter, (unsigned long long)segments);
         atomicAdd(a.segment_counter + 1, 64ull * rounds);
         if constexpr ((FT & F_BVH) != 0) {
-            atomicAdd(a.segment_counter + 2, (unsigned long long)wave_cost[0]);
-            atomicAdd(a.segment_counter + 3, (unsigned long long)wave_cost[1]);
-            atomicAdd(a.segment_counter + 4, (unsigned long long)wave_cost[2]);
+            if (a.count_cost) {
+                atomicAdd(a.segment_counter + 2, (unsigned long long)wave_words[0]);
+                atomicAdd(a.segment_counter + 3, (unsigned long long)wave_words[1]);
+                atomicAdd(a.segment_counter + 4, (unsigned long long)wave_words[2]);
+            }
         }
     }
 }
 
+hipError_t launch_reduce_chunks(const RenderArgs& a, hipStream_t stream);
 // max_depth == 0: ray_color returns black at once (renderer.rs:198-200); the samples still count.
 __global__ __launch_bounds__(kBlock) void count_samples_kernel(float4* accum, uint32_t n, float spp) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
@@ -647,10 +651,7 @@ static hipError_t launch_persistent(Kernel kernel, const RenderArgs& a, hipStrea
     const uint32_t resident = (uint32_t)std::max(cus * per_cu, 1);
     hipLaunchKernelGGL(kernel, dim3(std::min(want, resident)), dim3(kBlock), 0, stream, a);
     if ((e = hipGetLastError()) != hipSuccess || a.n_chunks == 1) return e;
-    const uint32_t n = a.width * a.height;
-    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a.accum, a.partial, n, a.n_chunks,
-                       a.chunk_spp, a.spp_count, a.stamp, a.scene.fault);
-    return hipGetLastError();
+    return launch_reduce_chunks(a, stream);
 }
 
 template <uint32_t F>
@@ -747,6 +748,12 @@ bool render_uses_queue(const RenderArgs& a) {
 hipError_t launch_render_fused(const RenderArgs& a, hipStream_t stream) {
     if (a.width == 0 || a.height == 0 || a.spp_count == 0) return hipSuccess;
     return dispatch<RenderLauncher>(a.scene.features, a, stream);
+}
+hipError_t launch_reduce_chunks(const RenderArgs& a, hipStream_t stream) {
+    const uint32_t n = a.width * a.height;
+    hipLaunchKernelGGL(reduce_chunks_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a.accum, a.partial, n, a.n_chunks,
+                       a.chunk_spp, a.spp_count, a.stamp, a.scene.fault);
+    return hipGetLastError();
 }
 hipError_t launch_first_hit(const RayBatchArgs& a, hipStream_t stream) {
     if (a.n == 0) return hipSuccess;

@@ -644,6 +644,11 @@ int wf_alloc(mirt_ctx* c, T** out, size_t n) {
     return MIRT_OK;
 }
 
+// Path pool and queues of the wavefront kernel set for `slots` paths (grown on demand, never shrunk).
+uint32_t wf_lane_capacity(uint32_t slots) {
+    const uint32_t blocks = (slots + 255u) / 256u;
+    return ((blocks + WF_LANES - 1u) / WF_LANES) * 256u;
+}
 int wf_ensure(mirt_ctx* c, uint32_t slots) {
     if (c->wf_capacity >= slots) return MIRT_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -652,65 +657,65 @@ int wf_ensure(mirt_ctx* c, uint32_t slots) {
     c->wf_capacity = 0;
     int rc;
     WfState st{};
-    if ((rc = wf_alloc(c, &st.rayo, slots))) return rc;
-    if ((rc = wf_alloc(c, &st.rayd, slots))) return rc;
     if ((rc = wf_alloc(c, &st.thr, slots))) return rc;
+    if ((rc = wf_alloc(c, &st.acc, slots))) return rc;
     if ((rc = wf_alloc(c, &st.ids, slots))) return rc;
-    if ((rc = wf_alloc(c, &st.hit_t, slots))) return rc;
-    if ((rc = wf_alloc(c, &st.q_new, slots))) return rc;
-    if ((rc = wf_alloc(c, &st.q_cur, slots))) return rc;
-    if ((rc = wf_alloc(c, &st.q_next, slots))) return rc;
-    if ((rc = wf_alloc(c, &st.q_mat, (size_t)slots * WF_KINDS))) return rc;
-    if ((rc = wf_alloc(c, &st.counts, (size_t)WF_N_COUNTS))) return rc;
-    if (!c->wf_counts_host) HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->wf_counts_host), 2 * WF_N_COUNTS * sizeof(uint32_t)));
+    const size_t entries = (size_t)WF_LANES * wf_lane_capacity(slots);
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = wf_alloc(c, &st.q_o[k], entries))) return rc;
+        if ((rc = wf_alloc(c, &st.q_d[k], entries))) return rc;
+        if ((rc = wf_alloc(c, &st.q_h[k], entries))) return rc;
+    }
+    if ((rc = wf_alloc(c, &st.ctl, (size_t)WF_CTL_WORDS))) return rc;
+    if ((rc = wf_alloc(c, &st.cost, (size_t)WF_MAX_WALK_GROUPS * 4))) return rc;
+    HIP_TRY(c, hipMemset(st.cost, 0, (size_t)WF_MAX_WALK_GROUPS * 4 * sizeof(unsigned long long)));
+    if (!c->wf_counts_host) HIP_TRY(c, hipHostMalloc(reinterpret_cast<void**>(&c->wf_counts_host), WF_CTL_WORDS * sizeof(uint32_t)));
     c->wf = st;
     c->wf_capacity = slots;
     return MIRT_OK;
 }
 
-// generate -> extend -> shade per ray segment, driven from the host: after each iteration the queue
-// counters are read back (one small copy + stream sync) to size the next launches and detect the end.
-int render_wavefront(mirt_ctx* c, const mirt_render_params* p) {
-    const uint32_t n = p->width * p->height;
-    int rc = wf_ensure(c, n);
+// One launch of the sample loop (a.spp_count samples per pixel, chunked as a.n_chunks says) with the wavefront kernel
+// set: rounds are enqueued in batches without reading anything back; after a batch the live count of the pool comes
+// to the host, and the render is over when it is zero. Rounds enqueued past the end find empty queues and cost a
+// few microseconds each; the batches grow with the render so that neither they nor the read-backs matter.
+int render_wavefront_launch(mirt_ctx* c, const RenderArgs& a, uint32_t* launches) {
+    static const uint32_t pool = [] { const char* e = std::getenv("MIRT_WF_POOL"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : (1u << 22); }();
+    static const uint32_t refill = [] { const char* e = std::getenv("MIRT_WF_REFILL"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)std::min(v, 64l) : 16u; }();
+    static const uint32_t fetch_run = [] { const char* e = std::getenv("MIRT_WF_RUN"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 128u; }();
+    const uint64_t items = (uint64_t)((a.width + 7u) / 8u) * ((a.height + 7u) / 8u) * 64u * a.n_chunks;
+    if (items >= 0xffffff00ull) return fail(c, MIRT_ERR_INVALID, "mirt_render: too many work items for one launch");
+    const uint32_t capacity = (uint32_t)std::min<uint64_t>(pool, items);
+    int rc = wf_ensure(c, capacity);
     if (rc) return rc;
-    WfArgs a{};
-    a.scene = c->scene;
-    a.cam = c->cam;
-    a.accum = c->accum;
-    a.segment_counter = c->seg_counter;
-    a.width = p->width; a.height = p->height; a.capacity = c->wf_capacity;
-    a.sample_end = p->spp_begin + p->spp_count;
-    a.max_depth = p->max_depth; a.seed = p->seed; a.jitter = p->jitter;
-    uint32_t launches = 0;
-    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    if (p->spp_count && p->max_depth) {
-        a.st = c->wf;
-        HIP_TRY(c, wf_launch_reset(a.st, n, p->spp_begin, c->stream));
-        uint32_t n_new = n, n_cont = 0;
-        uint32_t* up = c->wf_counts_host;
-        uint32_t* down = c->wf_counts_host + WF_N_COUNTS;
-        while (n_new || n_cont) {
-            for (uint32_t i = 0; i < WF_N_COUNTS; ++i) up[i] = 0;
-            up[WF_N_CUR] = n_cont;
-            HIP_TRY(c, hipMemcpyAsync(a.st.counts, up, WF_N_COUNTS * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            a.n_new = n_new;
-            a.n_cur = n_cont + n_new;
-            HIP_TRY(c, wf_launch_generate(a, c->stream));
-            HIP_TRY(c, wf_launch_extend(a, c->stream));
-            HIP_TRY(c, wf_launch_shade(a, c->stream));
-            HIP_TRY(c, hipMemcpyAsync(down, a.st.counts, WF_N_COUNTS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            launches += 3;
-            n_new = down[WF_N_NEW];
-            n_cont = down[WF_N_NEXT];
-            std::swap(a.st.q_cur, a.st.q_next);
+    WfArgs w{};
+    w.r = a;
+    w.r.walk_budget = 0x7fffffffu;  // a walk's turn ends when a refill is due, not after a number of steps
+    // the walk kernel sizes its LDS stacks by what the scene's hierarchies need (a leaf at level L: L - 1 entries)
+    w.r.scene.stack_limit = std::min(w.r.scene.stack_limit, (uint32_t)std::max(c->bvh_deepest_leaf - 1, 1));
+    w.st = c->wf;
+    w.capacity = capacity;
+    w.lane_capacity = wf_lane_capacity(capacity);
+    w.refill_lanes = refill;
+    w.fetch_run = fetch_run;
+    HIP_TRY(c, wf_launch_init(w, c->stream));
+    ++*launches;
+    uint32_t round = 0, batch = 8;
+    for (;;) {
+        for (uint32_t k = 0; k < batch; ++k) {
+            w.round = round++;
+            HIP_TRY(c, wf_launch_round(w, c->stream));
+            *launches += 4;
         }
+        HIP_TRY(c, hipMemcpyAsync(c->wf_counts_host, w.st.ctl, WF_CTL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        uint64_t live = 0;
+        for (uint32_t k = 0; k < WF_LANES; ++k) live += c->wf_counts_host[k * WF_CTL_STRIDE + ((round & 1u) ? WF_CTL_N1 : WF_CTL_N0)];
+        if (live == 0) break;
+        batch = std::min(64u, std::max(8u, round / 4u));
     }
-    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
-    c->stats.samples += (uint64_t)n * p->spp_count;
-    c->stats.kernel_launches = launches;
-    c->stats.kernel_used = MIRT_KERNEL_WAVEFRONT;
+    HIP_TRY(c, wf_launch_finish(w, c->stream));
+    if (a.n_chunks > 1) HIP_TRY(c, launch_reduce_chunks(a, c->stream));
     return MIRT_OK;
 }
 }  // namespace
@@ -735,7 +740,8 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
     if (!c->accum || p->width != c->width || p->height != c->height)
         return fail(c, MIRT_ERR_STATE, w + ": width/height differ from mirt_frame_begin");
     if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, w + ": sample range overflows 32 bits");
-    if (p->kernel > MIRT_KERNEL_QUEUE) return fail(c, MIRT_ERR_INVALID, w + ": unknown kernel selector");
+    if ((p->kernel & 0xffu) > MIRT_KERNEL_QUEUE || (p->kernel & ~(0xffu | MIRT_KERNEL_COUNT_WALKS))) return fail(c, MIRT_ERR_INVALID, w + ": unknown kernel selector");
+    const uint32_t selector = p->kernel & 0xffu;
     HIP_TRY(c, hipSetDevice(c->device));
     RenderArgs a{};
     a.scene = c->scene;
@@ -745,7 +751,10 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
     a.accum = c->accum;
     a.segment_counter = c->seg_counter;
     a.work_counter = sc.work_counter;
-    a.loop = p->kernel == MIRT_KERNEL_FUSED ? LOOP_FUSED : (p->kernel == MIRT_KERNEL_QUEUE ? LOOP_QUEUE : LOOP_AUTO);
+    a.loop = selector == MIRT_KERNEL_FUSED ? LOOP_FUSED : (selector == MIRT_KERNEL_QUEUE ? LOOP_QUEUE : LOOP_AUTO);
+    a.count_cost = (p->kernel & MIRT_KERNEL_COUNT_WALKS) ? 1u : 0u;
+    // depth 0 traces nothing (renderer.rs:198-200): the other kernels just count the samples
+    const bool wavefront = selector == MIRT_KERNEL_WAVEFRONT && p->max_depth > 0 && sc.may_allocate;
     // the persistent kernel packs a pixel position into 16 + 16 bits: larger frames go to the one-pixel-per-lane kernel
     if (p->width > 0xffffu || p->height > 0xffffu) a.loop = LOOP_FUSED;
     a.debug_drop_pixel = 0xffffffffu;
@@ -779,7 +788,7 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
         a.spp_count = std::min(kChunk, p->spp_count - done);
         a.n_chunks = 1;
         a.chunk_spp = a.spp_count;
-        if (render_uses_queue(a) && a.max_depth > 0 && split > 1 && a.spp_count > 1) {
+        if ((render_uses_queue(a) || wavefront) && a.max_depth > 0 && split > 1 && a.spp_count > 1) {
             // The persistent kernel hands out (pixel, sample chunk) items: with whole pixels as items the launch
             // lasts as long as its most expensive pixel (measured on `final`: the average wave was alive for 46 %
             // of the kernel's duration, the rest was the tail of the pixels on the sphere cluster).
@@ -806,6 +815,11 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
         if (++c->stamp == 0) c->stamp = 1;
         // (a stamp is a float's bit pattern in a slot nobody reads as a float; it only has to differ from launch to launch)
         a.stamp = c->stamp;
+        if (wavefront) {
+            const int rc = render_wavefront_launch(c, a, &launches);
+            if (rc) return rc;
+            continue;
+        }
         HIP_TRY(c, hipMemsetAsync(a.work_counter, 0, kWorkCounterBytes, c->stream));
         HIP_TRY(c, launch_render_fused(a, c->stream));
         ++launches;
@@ -813,22 +827,12 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     c->stats.samples += (uint64_t)p->width * p->height * p->spp_count;
     c->stats.kernel_launches = launches;
-    c->stats.kernel_used = render_uses_queue(a) ? MIRT_KERNEL_QUEUE : MIRT_KERNEL_FUSED;
+    c->stats.kernel_used = wavefront ? MIRT_KERNEL_WAVEFRONT : (render_uses_queue(a) ? MIRT_KERNEL_QUEUE : MIRT_KERNEL_FUSED);
     return MIRT_OK;
 }
 
 int mirt_render(mirt_ctx* c, const mirt_render_params* p) {
     if (!c) return MIRT_ERR_INVALID;
-    // depth 0 traces nothing (renderer.rs:198-200): the fused kernel just counts the samples
-    if (p && p->kernel == MIRT_KERNEL_WAVEFRONT && p->max_depth > 0) {
-        if (!c->has_scene) return fail(c, MIRT_ERR_STATE, "mirt_render: no scene uploaded");
-        if (!c->has_camera) return fail(c, MIRT_ERR_STATE, "mirt_render: no camera set");
-        if (!c->accum || p->width != c->width || p->height != c->height)
-            return fail(c, MIRT_ERR_STATE, "mirt_render: width/height differ from mirt_frame_begin");
-        if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, "mirt_render: sample range overflows 32 bits");
-        HIP_TRY(c, hipSetDevice(c->device));
-        return render_wavefront(c, p);
-    }
     return render_impl(c, p, "mirt_render", RenderScratch{work_counters(c), nullptr, 0, true});
 }
 

@@ -8,32 +8,47 @@
 
 namespace mirt {
 
-// One path per slot, structure of arrays (80 bytes per slot).
+// One path per slot, structure of arrays (48 bytes per slot): what only the shading stage reads.
+// The ray itself travels in the queue: an entry of a round's queue is the record of one live path —
+// its ray, the closest hit found so far, its slot (40 bytes, three arrays) — stored in queue order, so the
+// intersection stages read and write it with coalesced 16-byte accesses and never follow a slot index.
 struct WfState {
-    float4* rayo;  // origin.xyz, time
-    float4* rayd;  // direction.xyz, t of the closest hit so far
-    float4* thr;   // throughput.xyz, bits of the hit primitive (int, -1 = none)
+    float4* thr;   // throughput.xyz, -
     float4* acc;   // sample sums of the slot's work item .xyz, bits of its pixel position x | y << 16
     uint4* ids;    // pixel, sample, end of the item's sample range, bounce
-    uint32_t* q[2];  // live slots: round r reads q[r & 1] and fills q[(r + 1) & 1]
-    uint32_t* ctl;   // control words, WF_CTL_* (each in its own 128-byte line)
+    // queues: round r reads [r & 1] and fills [(r + 1) & 1]; WF_LANES lanes of `lane_capacity` entries each
+    float4* q_o[2];  // origin.xyz, time
+    float4* q_d[2];  // direction.xyz, t of the closest hit so far
+    uint2* q_h[2];   // bits of the hit primitive (int, -1 = none), slot
+    uint32_t* ctl;   // control words, WF_CTL_*
+    unsigned long long* cost;  // per workgroup of the walk kernel: node steps, leaf spheres, leaf rects, - (summed at the end)
 };
-// control words (indices of 32-bit words; a stride of 32 words keeps the contended ones in separate lines)
+constexpr uint32_t WF_MAX_WALK_GROUPS = 4096;
+// Every queue is WF_LANES independent lanes, and so is the hand-out of work items: a read-modify-write on one
+// address costs about 35 ns on this device however many waves queue for it (measured: 32 768 waves appending to one
+// counter made a kernel over 2 M paths last 1.2 ms), so the appends of a round are spread over 64 counters in
+// separate 128-byte lines. A workgroup reads lane (blockIdx mod WF_LANES) and appends to the same lane of the other
+// queue, so a lane never receives more than it held and `lane_capacity` bounds it for good.
+constexpr uint32_t WF_LANES = 64;
+// control words of lane k: ctl[k * WF_CTL_STRIDE + ...]
 enum : uint32_t {
-    WF_CTL_STRIDE = 32,
-    WF_CTL_N0 = 0 * WF_CTL_STRIDE,      // entries in q[0]
-    WF_CTL_N1 = 1 * WF_CTL_STRIDE,      // entries in q[1]
-    WF_CTL_CURSOR = 2 * WF_CTL_STRIDE,  // fetch position of the walk kernel in this round's queue
-    WF_CTL_ITEM = 3 * WF_CTL_STRIDE,    // next work item to hand out
-    WF_CTL_WORDS = 4 * WF_CTL_STRIDE,
+    WF_CTL_STRIDE = 32,  // 128 bytes
+    WF_CTL_N0 = 0,       // entries in lane k of q[0]
+    WF_CTL_N1 = 1,       // entries in lane k of q[1]
+    WF_CTL_CURSOR = 2,   // fetch position of the walk kernel in lane k of this round's queue
+    WF_CTL_ITEM = 3,     // work items handed out by counter k
+    WF_CTL_WORDS = (WF_LANES + 1) * WF_CTL_STRIDE,
+    WF_CTL_ITEMS_SPENT = WF_LANES * WF_CTL_STRIDE,  // two words: which item counters were spent when the round began
 };
 
 struct WfArgs {
     RenderArgs r;       // scene, camera, frame, sample range, chunking (n_chunks, chunk_spp, partial, stamp), statistics
     WfState st;
     uint32_t capacity;  // slots in the pool
+    uint32_t lane_capacity;  // entries per queue lane: 256 x the workgroups of the pool that map to one lane
     uint32_t round;     // parity selects the queues
     uint32_t refill_lanes;  // the walk kernel fetches new rays when this many lanes of a wave are idle
+    uint32_t fetch_run;     // ... out of a run of this many queue entries the wave reserves with one atomic
 };
 
 // Slots 0 .. capacity - 1 take the first work items, get their camera rays and fill q[0].
@@ -41,5 +56,7 @@ hipError_t wf_launch_init(const WfArgs& a, hipStream_t stream);
 // One round: closest hit of every live path (list scan, then the persistent hierarchy walk), then shading /
 // scattering / next sample / next item, which fills the other queue.
 hipError_t wf_launch_round(const WfArgs& a, hipStream_t stream);
+// End of a render: the walk kernel's per-workgroup cost words go to the statistics block.
+hipError_t wf_launch_finish(const WfArgs& a, hipStream_t stream);
 
 }  // namespace mirt

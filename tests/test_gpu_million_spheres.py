@@ -124,9 +124,19 @@ def test_full_size_pass_properties(rt, oracle):
     assert (q[0][..., 3] == 1).all() and (q[0] == f[0]).all()
     assert q[1]["segments"] == f[1]["segments"]
     assert np.isfinite(q[0]).all() and q[0][..., :3].mean() > 0.05
-    # the walk statistics are plausible: tens of node visits per segment, about one leaf sphere test per few nodes
-    nodes = q[1]["bvh_node_steps"] / q[1]["segments"]
-    assert 10 < nodes < 120 and 0 < q[1]["bvh_sphere_tests"] < q[1]["bvh_node_steps"]
+    assert q[1]["bvh_node_steps"] == 0                     # nothing is tallied unless asked for
+    # a counting pass: same image, and plausible walk statistics — tens of interior nodes per segment, a leaf sphere
+    # for every few of them — identical from the persistent kernel and the wavefront walk kernel (same walks)
+    tallies = []
+    for k in (rt.KERNEL_QUEUE, rt.KERNEL_WAVEFRONT):
+        ctx.frame_begin(W, H)
+        ctx.render(1, 10, seed=6, jitter=False, kernel=k | rt.KERNEL_COUNT_WALKS)
+        st = ctx.stats()
+        assert (ctx.read_accum() == q[0]).all() and st["segments"] == q[1]["segments"]
+        tallies.append((st["bvh_node_steps"], st["bvh_sphere_tests"], st["bvh_rect_tests"]))
+        nodes = st["bvh_node_steps"] / st["segments"]
+        assert 10 < nodes < 120 and 0.5 * st["segments"] < st["bvh_sphere_tests"] < st["bvh_node_steps"] and st["bvh_rect_tests"] == 0
+    assert tallies[0] == tallies[1]
     # a second pass on top: progressive refinement keeps adding
     ctx.frame_begin(W, H)
     for s in range(2):
