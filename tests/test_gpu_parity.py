@@ -149,6 +149,12 @@ def test_accumulated_image_matches_oracle(rt, oracle, earth, name, spp, depth):
         assert abs(st["segments"] - int(cnt[0])) <= 0.002 * int(cnt[0]) + 2  # same paths -> same segment count
     close = np.isclose(got, want, rtol=5e-3, atol=5e-3 * spp * 0.05)
     assert close.all(axis=2).mean() > 0.97
+    # A pixel that is not close holds a path that a last-bit difference diverted (another side of an edge, a free
+    # path that ends a hair earlier): its SUM then differs by what one sample can carry, not by an arbitrary amount.
+    # One sample carries at most the brightest source of the scene times a weight of order one: measured worst cases
+    # over four seeds are 6.1 (cornell, emitter 15), 2.0 (random, sky 1), 15 (final, emitter 15); the cap is 4 sources.
+    brightest = {"cornell": 15.0, "smoke": 7.0, "final": 15.0, "simplelight": 4.0}.get(name, 1.0)
+    assert np.abs(got - want).max() <= 4.0 * brightest, np.abs(got - want).max()
     mean_g, mean_o = got.mean() / spp, want.mean() / spp
     assert abs(mean_g - mean_o) <= 0.01 * mean_o + 1e-4
 
