@@ -204,4 +204,77 @@ class BvhBuilder {
     }
 };
 
+// Collapses the binary tree rooted at nodes2[root2] into four-wide nodes appended to nodes4: every node takes the
+// children of its interior children in their place (2 to 4 children, in the binary tree's order). Returns the new
+// root's index; *stack_need receives the most references a walk of the new tree can have pushed at once — a step
+// pushes every hit child but the one it enters, so a node with k children adds k - 1 to the deepest need below it.
+inline uint32_t collapse_to_four(const std::vector<DevBvhNode>& nodes2, uint32_t root2, std::vector<DevBvhNode4>& nodes4, uint32_t* stack_need) {
+    struct Child {
+        float lo[3], hi[3];
+        uint32_t ref;
+    };
+    auto children_of = [&](uint32_t n, Child out[2]) {
+        const DevBvhNode& b = nodes2[n];
+        out[0] = Child{{b.lo0x, b.lo0y, b.lo0z}, {b.hi0x, b.hi0y, b.hi0z}, b.ref0};
+        out[1] = Child{{b.lo1x, b.lo1y, b.lo1z}, {b.hi1x, b.hi1y, b.hi1z}, b.ref1};
+    };
+    // explicit work list: (binary node, index of its four-wide node); needs are filled on the way back
+    struct Item { uint32_t n2, n4; };
+    std::vector<Item> todo;
+    const uint32_t root4 = (uint32_t)nodes4.size();
+    nodes4.emplace_back();
+    todo.push_back({root2, root4});
+    std::vector<uint32_t> made;  // four-wide nodes of this tree in creation order (parents before children)
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        made.push_back(it.n4);
+        Child two[2], kids[4];
+        int k = 0;
+        children_of(it.n2, two);
+        for (int c = 0; c < 2; ++c) {
+            if (two[c].ref == 0xffffffffu) continue;           // the missing second child of a single-leaf tree
+            if (two[c].ref & 0x80000000u) { kids[k++] = two[c]; continue; }
+            Child grand[2];
+            children_of(two[c].ref, grand);
+            for (int g = 0; g < 2; ++g)
+                if (grand[g].ref != 0xffffffffu) kids[k++] = grand[g];
+        }
+        DevBvhNode4 nd{};
+        for (int i = 0; i < 4; ++i) {
+            const bool have = i < k;
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            uint32_t ref = 0xffffffffu;
+            if (have) {
+                for (int a = 0; a < 3; ++a) { lo[a] = kids[i].lo[a]; hi[a] = kids[i].hi[a]; }
+                ref = kids[i].ref;
+                if (!(ref & 0x80000000u)) {                     // interior: its own four-wide node
+                    const uint32_t n4 = (uint32_t)nodes4.size();
+                    nodes4.emplace_back();
+                    todo.push_back({ref, n4});
+                    ref = n4;
+                }
+            }
+            nd.xy[i][0] = lo[0]; nd.xy[i][1] = lo[1]; nd.xy[i][2] = hi[0]; nd.xy[i][3] = hi[1];
+            float* z = i < 2 ? nd.z01 : nd.z23;
+            z[(i & 1) * 2] = lo[2]; z[(i & 1) * 2 + 1] = hi[2];
+            nd.ref[i] = ref;
+        }
+        nd.pad[0] = (uint32_t)k;
+        nodes4[it.n4] = nd;
+    }
+    // needs, children before parents (reverse creation order); pad[1] holds a node's need while this runs
+    uint32_t need_root = 0;
+    for (size_t i = made.size(); i-- > 0;) {
+        DevBvhNode4& nd = nodes4[made[i]];
+        uint32_t below = 0;
+        for (int c = 0; c < 4; ++c)
+            if (nd.ref[c] != 0xffffffffu && !(nd.ref[c] & 0x80000000u)) below = std::max(below, nodes4[nd.ref[c]].pad[1]);
+        nd.pad[1] = below + (nd.pad[0] > 0 ? nd.pad[0] - 1u : 0u);
+        need_root = nd.pad[1];
+    }
+    *stack_need = need_root;
+    return root4;
+}
+
 }  // namespace mirt

@@ -486,41 +486,57 @@ MIRT_DEV void walk_pop(Walk& w, const uint32_t* stack, uint32_t stride) {
     if (w.sp) w.ref = stack[(--w.sp) * stride];
 }
 
-// BVHNode::hit (aabb.rs:112-126) for one interior node: test both child boxes against [t_min, closest] (the
-// slab test of aabb.rs:43-60), continue with the nearer hit child and push the other. The twelve plane
-// distances are six packed fused multiply-adds, t = p * rinv + (-origin * rinv): half the issue time of packed
-// subtract-then-multiply. That form errs by 2^-24 (|origin * rinv| + |t|) instead of a few ulp of t; the boxes
-// are stored padded by 2^-21 of the hierarchy's largest coordinate, which covers the first term for origins
-// within the scene, and the far bound is widened by 16 ulp, which covers the second, the first for origins far
-// outside (there |origin * rinv| is about |t|) and the 1-ulp reciprocals — so the test stays conservative and
-// the closest hit is unchanged. `stack` is this lane's column of an LDS array laid out [level][lane] (stride =
-// blockDim.x words): pushes and pops are conflict-free.
+// BVHNode::hit (aabb.rs:112-126) for one four-wide node, i.e. for a node of the reference's binary tree and its
+// interior children at once: test the (up to) four child boxes against [t_min, closest] (the slab test of
+// aabb.rs:43-60), continue with the nearest hit child and push the other hit ones. The 24 plane distances are twelve
+// packed fused multiply-adds, t = p * rinv + (-origin * rinv): half the issue time of packed subtract-then-multiply.
+// That form errs by 2^-24 (|origin * rinv| + |t|) instead of a few ulp of t; the boxes are stored padded by 2^-21 of
+// the hierarchy's largest coordinate, which covers the first term for origins within the scene, and the far bound is
+// widened by 16 ulp, which covers the second, the first for origins far outside (there |origin * rinv| is about
+// |t|) and the 1-ulp reciprocals — so the test stays conservative and the closest hit is unchanged.
+// The nearest child comes out of a tournament of three comparisons on (entry distance, reference) pairs — (0, 1),
+// (2, 3), then the winners — whose losers are the references to push: no sorting network, no index arithmetic. The
+// pair losers go on the stack first and the loser of the final last, so the second-nearest is usually popped next.
+// `stack` is this lane's column of an LDS array laid out [level][lane] (stride = blockDim.x words): pushes and pops
+// are conflict-free.
+// Entry distance of one child box, +inf when the ray misses it or the child does not exist.
+MIRT_DEV float child_entry(f32x2 lo_xy, f32x2 hi_xy, f32x2 z, uint32_t ref, float t_min, float closest) {
+    const float tn = fmaxf(fmaxf(fminf(lo_xy.x, hi_xy.x), fminf(lo_xy.y, hi_xy.y)), fmaxf(fminf(z.x, z.y), t_min));
+    const float tf = fminf(fminf(fmaxf(lo_xy.x, hi_xy.x), fmaxf(lo_xy.y, hi_xy.y)), fminf(fmaxf(z.x, z.y), closest));
+    // (a missing child has no reference; its empty box would pass the test)
+    return ((tn <= tf * 1.000002f) & (ref != kWalkIdle)) ? tn : MIRT_INF;
+}
+MIRT_DEV void walk_push(const DevScene& s, Walk& w, uint32_t* stack, uint32_t stride, bool on, uint32_t ref) {
+    if (on) {
+        // (the host sizes the stacks by the exact need of every hierarchy it builds; a full stack here means that
+        // promise was broken, and the dropped child is reported instead of silently missed)
+        if (w.sp < s.stack_limit) stack[(w.sp++) * stride] = ref;
+        else atomicOr(s.fault, (uint32_t)FAULT_STACK_OVERFLOW);
+    }
+}
 MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w, uint32_t* stack, uint32_t stride) {
     const float4* q = reinterpret_cast<const float4*>(s.bvh_nodes + w.ref);
-    const float4 a = q[0], b = q[1], c = q[2];
-    const uint4 refs = reinterpret_cast<const uint4*>(q)[3];
+    const float4 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3], z01 = q[4], z23 = q[5];
+    const uint4 refs = reinterpret_cast<const uint4*>(q)[6];
     const f32x2 cxy = {nc.x, nc.y}, czz = {nc.z, nc.z};
     const f32x2 rxy = {rinv.x, rinv.y}, rzz = {rinv.z, rinv.z};
-    const f32x2 l0 = __builtin_elementwise_fma(f32x2{a.x, a.y}, rxy, cxy), h0 = __builtin_elementwise_fma(f32x2{a.z, a.w}, rxy, cxy);
-    const f32x2 l1 = __builtin_elementwise_fma(f32x2{b.x, b.y}, rxy, cxy), h1 = __builtin_elementwise_fma(f32x2{b.z, b.w}, rxy, cxy);
-    const f32x2 z0 = __builtin_elementwise_fma(f32x2{c.x, c.y}, rzz, czz), z1 = __builtin_elementwise_fma(f32x2{c.z, c.w}, rzz, czz);
-    const float tn0 = fmaxf(fmaxf(fminf(l0.x, h0.x), fminf(l0.y, h0.y)), fmaxf(fminf(z0.x, z0.y), t_min));
-    const float tf0 = fminf(fminf(fmaxf(l0.x, h0.x), fmaxf(l0.y, h0.y)), fminf(fmaxf(z0.x, z0.y), w.closest));
-    const float tn1 = fmaxf(fmaxf(fminf(l1.x, h1.x), fminf(l1.y, h1.y)), fmaxf(fminf(z1.x, z1.y), t_min));
-    const float tf1 = fminf(fminf(fmaxf(l1.x, h1.x), fmaxf(l1.y, h1.y)), fminf(fmaxf(z1.x, z1.y), w.closest));
-    // (the missing second child of a single-leaf tree has no reference; its empty box would pass the test)
-    const bool hit0 = tn0 <= tf0 * 1.000002f, hit1 = (tn1 <= tf1 * 1.000002f) & (refs.y != kWalkIdle);
-    if (hit0 && hit1) {
-        const bool first0 = tn0 <= tn1;
-        w.ref = first0 ? refs.x : refs.y;
-        // (the host checks the depth of every hierarchy it builds against the stack at upload; a full stack here
-        // means that promise was broken, and the dropped child is reported instead of silently missed)
-        if (w.sp < s.stack_limit) stack[(w.sp++) * stride] = first0 ? refs.y : refs.x;
-        else atomicOr(s.fault, (uint32_t)FAULT_STACK_OVERFLOW);
-    } else if (hit0) {
-        w.ref = refs.x;
-    } else if (hit1) {
-        w.ref = refs.y;
+#define MIRT_CHILD(b, zlo, zhi, ref)                                                                              \
+    child_entry(__builtin_elementwise_fma(f32x2{b.x, b.y}, rxy, cxy), __builtin_elementwise_fma(f32x2{b.z, b.w}, rxy, cxy), \
+                __builtin_elementwise_fma(f32x2{zlo, zhi}, rzz, czz), ref, t_min, w.closest)
+    const float k0 = MIRT_CHILD(b0, z01.x, z01.y, refs.x), k1 = MIRT_CHILD(b1, z01.z, z01.w, refs.y);
+    const float k2 = MIRT_CHILD(b2, z23.x, z23.y, refs.z), k3 = MIRT_CHILD(b3, z23.z, z23.w, refs.w);
+#undef MIRT_CHILD
+    const bool f01 = k0 <= k1, f23 = k2 <= k3;
+    const float ka = f01 ? k0 : k1, la = f01 ? k1 : k0, kb = f23 ? k2 : k3, lb = f23 ? k3 : k2;
+    const uint32_t ra = f01 ? refs.x : refs.y, pa = f01 ? refs.y : refs.x, rb = f23 ? refs.z : refs.w, pb = f23 ? refs.w : refs.z;
+    const bool fab = ka <= kb;
+    const float kn = fab ? ka : kb, lf = fab ? kb : ka;
+    const uint32_t rn = fab ? ra : rb, pf = fab ? rb : ra;
+    if (kn < MIRT_INF) {
+        walk_push(s, w, stack, stride, la < MIRT_INF, pa);
+        walk_push(s, w, stack, stride, lb < MIRT_INF, pb);
+        walk_push(s, w, stack, stride, lf < MIRT_INF, pf);
+        w.ref = rn;
     } else {
         walk_pop(w, stack, stride);
     }

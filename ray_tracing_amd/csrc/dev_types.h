@@ -94,10 +94,12 @@ struct __attribute__((aligned(16))) DevPerlin {
     uint8_t perm[3][256];
 };
 
-// Entries of the per-lane traversal stack (LDS, [level][lane]). A walk pushes at most one reference per interior
-// node on its way down, so a hierarchy whose deepest leaf sits at level d (root = level 1) needs d - 1 entries;
-// the upload code builds with this bound and refuses a tree that exceeds it.
+// Depth bound of the binary trees the builder makes (root node = level 1) before they are collapsed into four-wide
+// nodes, and the largest per-lane traversal stack (LDS, [level][lane]) a kernel is launched with. A walk pushes up
+// to three references per four-wide node on its way down; the upload code computes the exact bound of every tree
+// (DevScene::stack_limit, which sizes the kernels' dynamic LDS) and refuses a scene that exceeds kBvhStackMax.
 constexpr int kBvhStackDepth = 32;
+constexpr int kBvhStackMax = 64;
 
 enum : uint32_t { EK_LIST = 0, EK_BVH = 1 };
 struct __attribute__((aligned(16))) DevEntry {
@@ -111,9 +113,8 @@ struct __attribute__((aligned(16))) DevEntry {
     uint32_t scan_count;
 };
 
-// 64-byte node holding the boxes of both children, so one interior step is one 64-byte fetch (four
-// 16-byte loads). The box coordinates are grouped in the pairs the slab test consumes with packed
-// two-float arithmetic: (x, y) of each corner, and (lo.z, hi.z) of each box.
+// The builder's 64-byte binary node: the boxes of both children and their references (host side only; the device
+// walks the four-wide nodes below, which are collapsed from these).
 // ref_i is the reference a walk continues with when it enters child i: an interior node index, or
 // bit 31 | (records - 1) << 27 | first record for a leaf of up to 16 primitive records in bvh_leaves.
 // A missing second child (single-leaf tree) has an empty box (lo = +inf, hi = -inf).
@@ -124,6 +125,19 @@ struct __attribute__((aligned(16))) DevBvhNode {
     uint32_t ref0, ref1, pad0, pad1;
 };
 static_assert(sizeof(DevBvhNode) == 64, "DevBvhNode is four 16-byte quads");
+
+// 128-byte node (one cache line, seven 16-byte loads) holding the boxes of up to four children: a binary node with
+// its interior children replaced by THEIR children, so a walk takes one step, one dependent fetch, where the binary
+// tree took two or three. The box coordinates are grouped in the pairs the slab test consumes with packed two-float
+// arithmetic: xy[i] = (lo.x, lo.y, hi.x, hi.y) of child i, z01 = (lo.z, hi.z) of children 0 and 1, z23 of 2 and 3.
+// A missing child has an empty box and the reference 0xffffffff.
+struct __attribute__((aligned(128))) DevBvhNode4 {
+    float xy[4][4];
+    float z01[4], z23[4];
+    uint32_t ref[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(DevBvhNode4) == 128, "DevBvhNode4 is one 128-byte line");
 
 enum : uint32_t { MK_LAMBERTIAN = 0, MK_METAL = 1, MK_DIELECTRIC = 2, MK_DIFFUSE_LIGHT = 3, MK_ISOTROPIC = 4 };
 enum : uint32_t { TK_SOLID = 0, TK_CHECKER = 1, TK_NOISE = 2, TK_IMAGE = 3 };
@@ -151,7 +165,7 @@ struct DevScene {
     const DevImage* images;
     const DevPerlin* perlins;
     const DevInstance* instances;
-    const DevBvhNode* bvh_nodes;
+    const DevBvhNode4* bvh_nodes;
     const DevLeafRec* bvh_leaves;  // leaf primitive records in tree order
     const uint32_t* bvh_entries;   // indices into entries of the EK_BVH ones, in world order
     uint32_t n_bvh_entries;
@@ -161,7 +175,8 @@ struct DevScene {
     float background[3];
     // Device-side diagnostics. `fault` points at one word the kernels OR bits into when they meet a state the host
     // promised could not occur (FAULT_*); the host reads it back with the statistics and in the blocking resolve.
-    // stack_limit = entries of the per-lane traversal stack a walk may use (kBvhStackDepth unless a test lowers it).
+    // stack_limit = entries of the per-lane traversal stack the scene's deepest walk can need (the kernels' LDS stacks
+    // are launched with that many levels; a test may lower it to see the overflow report).
     uint32_t* fault;
     uint32_t stack_limit;
 };

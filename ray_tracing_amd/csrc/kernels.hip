@@ -176,7 +176,7 @@ __device__ __forceinline__ void finish_pixel(const RenderArgs& a, bool valid, ui
 // per block and shading reads them there. PINHOLE: lens radius 0 and nothing moves.
 template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
 __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(RenderArgs a) {
-    __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
+    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit][kBlock], sized at the launch
     __shared__ DevPrim s_prims[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevShade s_shade[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevInstance s_inst[LDS_TABLES ? kLdsInstances : 1];
@@ -291,7 +291,7 @@ template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
 __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(RenderArgs a) {
     // the LDS-table variants are only launched for scenes without a hierarchy: no traversal code, no stack
     constexpr uint32_t FT = LDS_TABLES ? (F & ~(uint32_t)F_BVH) : F;
-    __shared__ uint32_t bvh_stack[(FT & F_BVH) ? kBvhStackDepth * kBlock : 1];
+    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit][kBlock], sized at the launch
     __shared__ DevPrim s_prims[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevShade s_shade[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevInstance s_inst[LDS_TABLES ? kLdsInstances : 1];
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void reduce_chunks_kernel(float4* accum, co
 
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
-    __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
+    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit][kBlock], sized at the launch
     uint32_t* stack = bvh_stack + threadIdx.x;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
 
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) void ray_color_kernel(RayBatchArgs a) {
-    __shared__ uint32_t bvh_stack[(F & F_BVH) ? kBvhStackDepth * kBlock : 1];
+    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit][kBlock], sized at the launch
     uint32_t* stack = bvh_stack + threadIdx.x;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
@@ -636,20 +636,26 @@ static hipError_t dispatch(uint32_t features, const Args& a, hipStream_t stream)
 
 // A persistent launch: as many workgroups as the device keeps resident at once (never more than the
 // frame has work for); the waves share out the pixels through a.work_counter, which the caller zeroed.
+// LDS bytes of the per-lane traversal stacks of one workgroup: [scene.stack_limit][kBlock] words, none for a scene
+// without a hierarchy.
+static uint32_t stack_bytes(const DevScene& s) {
+    return (s.features & F_BVH) ? s.stack_limit * kBlock * (uint32_t)sizeof(uint32_t) : 0u;
+}
+
 template <class Kernel>
 static hipError_t launch_persistent(Kernel kernel, const RenderArgs& a, hipStream_t stream) {
     int device = 0, cus = 0, per_cu = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
-    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, 0)) != hipSuccess) return e;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, stack_bytes(a.scene))) != hipSuccess) return e;
     const uint64_t items = (uint64_t)((a.width + 7u) / 8u) * ((a.height + 7u) / 8u) * 64u * a.n_chunks;
     if (a.n_chunks == 0 || items >= 0xffffff00ull || (uint64_t)a.n_chunks * a.width * a.height >= 0xffffffffull ||
         (a.n_chunks > 1 && !a.partial))
         return hipErrorInvalidValue;
     const uint32_t want = (uint32_t)((items + kBlock - 1) / kBlock);
     const uint32_t resident = (uint32_t)std::max(cus * per_cu, 1);
-    hipLaunchKernelGGL(kernel, dim3(std::min(want, resident)), dim3(kBlock), 0, stream, a);
+    hipLaunchKernelGGL(kernel, dim3(std::min(want, resident)), dim3(kBlock), stack_bytes(a.scene), stream, a);
     if ((e = hipGetLastError()) != hipSuccess || a.n_chunks == 1) return e;
     return launch_reduce_chunks(a, stream);
 }
@@ -678,24 +684,24 @@ struct RenderLauncher {
             if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, a, stream);
             return launch_persistent(render_queue_kernel<F, false, false>, a, stream);
         }
-        if (lds && pinhole) hipLaunchKernelGGL((render_fused_kernel<F, true, true>), grid, block, 0, stream, a);
-        else if (lds) hipLaunchKernelGGL((render_fused_kernel<F, true, false>), grid, block, 0, stream, a);
-        else if (pinhole) hipLaunchKernelGGL((render_fused_kernel<F, false, true>), grid, block, 0, stream, a);
-        else hipLaunchKernelGGL((render_fused_kernel<F, false, false>), grid, block, 0, stream, a);
+        if (lds && pinhole) hipLaunchKernelGGL((render_fused_kernel<F, true, true>), grid, block, stack_bytes(s), stream, a);
+        else if (lds) hipLaunchKernelGGL((render_fused_kernel<F, true, false>), grid, block, stack_bytes(s), stream, a);
+        else if (pinhole) hipLaunchKernelGGL((render_fused_kernel<F, false, true>), grid, block, stack_bytes(s), stream, a);
+        else hipLaunchKernelGGL((render_fused_kernel<F, false, false>), grid, block, stack_bytes(s), stream, a);
         return hipGetLastError();
     }
 };
 template <uint32_t F>
 struct FirstHitLauncher {
     static hipError_t run(const RayBatchArgs& a, hipStream_t stream) {
-        hipLaunchKernelGGL(first_hit_kernel<F>, dim3((a.n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL(first_hit_kernel<F>, dim3((a.n + kBlock - 1) / kBlock), dim3(kBlock), stack_bytes(a.scene), stream, a);
         return hipGetLastError();
     }
 };
 template <uint32_t F>
 struct RayColorLauncher {
     static hipError_t run(const RayBatchArgs& a, hipStream_t stream) {
-        hipLaunchKernelGGL(ray_color_kernel<F>, dim3((a.n + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, a);
+        hipLaunchKernelGGL(ray_color_kernel<F>, dim3((a.n + kBlock - 1) / kBlock), dim3(kBlock), stack_bytes(a.scene), stream, a);
         return hipGetLastError();
     }
 };

@@ -408,7 +408,8 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     for (uint32_t li : lights) light_prims.push_back(prims[li]);
     // ---- world entries + BVHs
     std::vector<DevEntry> entries(d->n_world);
-    std::vector<DevBvhNode> nodes;
+    std::vector<DevBvhNode4> nodes;   // four-wide nodes of all hierarchies
+    uint32_t stack_need = 1;
     std::vector<uint32_t> slots;          // first primitive of every leaf record, in tree order
     std::vector<uint8_t> slot_is_cuboid;  // the record stands for the six rects of a cuboid
     int deepest_leaf = 0;
@@ -476,13 +477,17 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
             float reach = 0.f;
             for (const BuildObject& o : objs)
                 for (int a = 0; a < 3; ++a) reach = std::max(reach, std::max(std::fabs(o.lo[a]), std::fabs(o.hi[a])));
-            BvhBuilder builder(nodes, slots, kBvhStackDepth, records_per_object, std::isfinite(reach) ? reach * 4.76837158e-7f : 0.f);
-            q.bvh_root = builder.build(objs);
-            // a walk pushes at most once per interior level: leaves at level L need L - 1 stack entries
+            // a binary tree first (binned SAH, depth <= kBvhStackDepth), then two levels of it per four-wide node
+            std::vector<DevBvhNode> binary;
+            BvhBuilder builder(binary, slots, kBvhStackDepth, records_per_object, std::isfinite(reach) ? reach * 4.76837158e-7f : 0.f);
+            const uint32_t root2 = builder.build(objs);
+            uint32_t need = 0;
+            q.bvh_root = collapse_to_four(binary, root2, nodes, &need);
             deepest_leaf = std::max(deepest_leaf, builder.deepest_leaf());
-            if (builder.deepest_leaf() - 1 > kBvhStackDepth)
-                return bad("entry " + std::to_string(e) + ": hierarchy is " + std::to_string(builder.deepest_leaf()) +
-                           " levels deep, the traversal stack holds " + std::to_string(kBvhStackDepth));
+            stack_need = std::max(stack_need, need);
+            if (need > (uint32_t)kBvhStackMax)
+                return bad("entry " + std::to_string(e) + ": a walk of this hierarchy can hold " + std::to_string(need) +
+                           " references, the traversal stack at most " + std::to_string(kBvhStackMax));
             slot_is_cuboid.resize(slots.size(), cuboids ? 1 : 0);  // marks the slots this entry added
             // the hit record of a BVH member is rebuilt with the entry's transform
             for (uint32_t k = 0; k < w.prim_count; ++k) prims[w.first_prim + k].instance = w.instance;
@@ -563,9 +568,9 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     s.features = features;
     for (int a = 0; a < 3; ++a) s.background[a] = d->background[a];
     s.fault = fault_word(c);
-    s.stack_limit = (uint32_t)kBvhStackDepth;
+    s.stack_limit = stack_need;   // what the deepest walk can need: the kernels' LDS stacks are launched this deep
     // (tests lower the limit to see the overflow report of walk_node)
-    if (const char* e = std::getenv("MIRT_DEBUG_STACK_LIMIT")) s.stack_limit = (uint32_t)std::min<long>(std::max<long>(std::atol(e), 0), kBvhStackDepth);
+    if (const char* e = std::getenv("MIRT_DEBUG_STACK_LIMIT")) s.stack_limit = (uint32_t)std::min<long>(std::max<long>(std::atol(e), 1), (long)stack_need);
     c->bvh_deepest_leaf = deepest_leaf;
     // what one scan of the world's list entries tests (a medium's boundary list is scanned at least once per scan
     // of the list that holds the medium): the per-segment list term of the algorithmic work
@@ -691,8 +696,6 @@ int render_wavefront_launch(mirt_ctx* c, const RenderArgs& a, uint32_t* launches
     WfArgs w{};
     w.r = a;
     w.r.walk_budget = 0x7fffffffu;  // a walk's turn ends when a refill is due, not after a number of steps
-    // the walk kernel sizes its LDS stacks by what the scene's hierarchies need (a leaf at level L: L - 1 entries)
-    w.r.scene.stack_limit = std::min(w.r.scene.stack_limit, (uint32_t)std::max(c->bvh_deepest_leaf - 1, 1));
     w.st = c->wf;
     w.capacity = capacity;
     w.lane_capacity = wf_lane_capacity(capacity);
