@@ -506,13 +506,13 @@ MIRT_DEV float child_entry(f32x2 lo_xy, f32x2 hi_xy, f32x2 z, uint32_t ref, floa
     // (a missing child has no reference; its empty box would pass the test)
     return ((tn <= tf * 1.000002f) & (ref != kWalkIdle)) ? tn : MIRT_INF;
 }
-MIRT_DEV void walk_push(const DevScene& s, Walk& w, uint32_t* stack, uint32_t stride, bool on, uint32_t ref) {
-    if (on) {
-        // (the host sizes the stacks by the exact need of every hierarchy it builds; a full stack here means that
-        // promise was broken, and the dropped child is reported instead of silently missed)
-        if (w.sp < s.stack_limit) stack[(w.sp++) * stride] = ref;
-        else atomicOr(s.fault, (uint32_t)FAULT_STACK_OVERFLOW);
-    }
+// A conditional push without a branch: the reference is always stored at the top of the stack and the stack pointer
+// moves only when `on` is set (three pushes of a node step are three stores and three predicated increments
+// instead of three divergent regions). The stack has three levels beyond s.stack_limit for the stores of a step
+// that starts at the limit; walk_node() checks the limit once, after the last push.
+MIRT_DEV void walk_push(Walk& w, uint32_t* stack, uint32_t stride, bool on, uint32_t ref) {
+    stack[w.sp * stride] = ref;
+    w.sp += on ? 1u : 0u;
 }
 MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w, uint32_t* stack, uint32_t stride) {
     const float4* q = reinterpret_cast<const float4*>(s.bvh_nodes + w.ref);
@@ -532,14 +532,17 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w,
     const bool fab = ka <= kb;
     const float kn = fab ? ka : kb, lf = fab ? kb : ka;
     const uint32_t rn = fab ? ra : rb, pf = fab ? rb : ra;
-    if (kn < MIRT_INF) {
-        walk_push(s, w, stack, stride, la < MIRT_INF, pa);
-        walk_push(s, w, stack, stride, lb < MIRT_INF, pb);
-        walk_push(s, w, stack, stride, lf < MIRT_INF, pf);
-        w.ref = rn;
-    } else {
-        walk_pop(w, stack, stride);
+    walk_push(w, stack, stride, la < MIRT_INF, pa);
+    walk_push(w, stack, stride, lb < MIRT_INF, pb);
+    walk_push(w, stack, stride, lf < MIRT_INF, pf);
+    // (the host sizes the stacks by the exact need of every hierarchy it builds; a stack beyond its limit means that
+    // promise was broken, and the dropped children are reported instead of silently missed)
+    if (w.sp > s.stack_limit) {
+        w.sp = s.stack_limit;
+        atomicOr(s.fault, (uint32_t)FAULT_STACK_OVERFLOW);
     }
+    if (kn < MIRT_INF) w.ref = rn;
+    else walk_pop(w, stack, stride);
 }
 
 // One primitive record of a leaf (the record's kind differs from lane to lane, so the rectangle's axes

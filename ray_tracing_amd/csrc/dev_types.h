@@ -100,6 +100,9 @@ struct __attribute__((aligned(16))) DevPerlin {
 // (DevScene::stack_limit, which sizes the kernels' dynamic LDS) and refuses a scene that exceeds kBvhStackMax.
 constexpr int kBvhStackDepth = 32;
 constexpr int kBvhStackMax = 64;
+// Levels of a launched stack beyond DevScene::stack_limit: the three pushes of a node step store before the limit is
+// checked (walk_push in dev_core.h).
+constexpr uint32_t kBvhStackSlack = 3;
 
 enum : uint32_t { EK_LIST = 0, EK_BVH = 1 };
 struct __attribute__((aligned(16))) DevEntry {

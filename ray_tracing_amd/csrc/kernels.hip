@@ -176,7 +176,7 @@ __device__ __forceinline__ void finish_pixel(const RenderArgs& a, bool valid, ui
 // per block and shading reads them there. PINHOLE: lens radius 0 and nothing moves.
 template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
 __global__ __launch_bounds__(kBlock, waves_for(F)) void render_fused_kernel(RenderArgs a) {
-    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit][kBlock], sized at the launch
+    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit + kBvhStackSlack][kBlock], sized at the launch
     __shared__ DevPrim s_prims[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevShade s_shade[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevInstance s_inst[LDS_TABLES ? kLdsInstances : 1];
@@ -291,7 +291,7 @@ template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
 __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(RenderArgs a) {
     // the LDS-table variants are only launched for scenes without a hierarchy: no traversal code, no stack
     constexpr uint32_t FT = LDS_TABLES ? (F & ~(uint32_t)F_BVH) : F;
-    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit][kBlock], sized at the launch
+    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit + kBvhStackSlack][kBlock], sized at the launch
     __shared__ DevPrim s_prims[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevShade s_shade[LDS_TABLES ? kLdsPrims : 1];
     __shared__ DevInstance s_inst[LDS_TABLES ? kLdsInstances : 1];
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void reduce_chunks_kernel(float4* accum, co
 
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
-    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit][kBlock], sized at the launch
+    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit + kBvhStackSlack][kBlock], sized at the launch
     uint32_t* stack = bvh_stack + threadIdx.x;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void first_hit_kernel(RayBatchArgs a) {
 
 template <uint32_t F>
 __global__ __launch_bounds__(kBlock) void ray_color_kernel(RayBatchArgs a) {
-    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit][kBlock], sized at the launch
+    extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit + kBvhStackSlack][kBlock], sized at the launch
     uint32_t* stack = bvh_stack + threadIdx.x;
     uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= a.n) return;
@@ -636,10 +636,10 @@ static hipError_t dispatch(uint32_t features, const Args& a, hipStream_t stream)
 
 // A persistent launch: as many workgroups as the device keeps resident at once (never more than the
 // frame has work for); the waves share out the pixels through a.work_counter, which the caller zeroed.
-// LDS bytes of the per-lane traversal stacks of one workgroup: [scene.stack_limit][kBlock] words, none for a scene
-// without a hierarchy.
+// LDS bytes of the per-lane traversal stacks of one workgroup: [scene.stack_limit + kBvhStackSlack][kBlock] words,
+// none for a scene without a hierarchy.
 static uint32_t stack_bytes(const DevScene& s) {
-    return (s.features & F_BVH) ? s.stack_limit * kBlock * (uint32_t)sizeof(uint32_t) : 0u;
+    return (s.features & F_BVH) ? (s.stack_limit + kBvhStackSlack) * kBlock * (uint32_t)sizeof(uint32_t) : 0u;
 }
 
 template <class Kernel>

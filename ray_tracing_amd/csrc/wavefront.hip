@@ -487,7 +487,7 @@ static hipError_t launch_round(const WfArgs& a, hipStream_t stream) {
     if constexpr ((F & F_BVH) != 0) {
         if (a.r.scene.n_bvh_entries) {
             uint32_t resident = 0;
-            const size_t lds_bytes = (size_t)std::max(a.r.scene.stack_limit, 1u) * kWfBlock * sizeof(uint32_t);
+            const size_t lds_bytes = (size_t)(a.r.scene.stack_limit + kBvhStackSlack) * kWfBlock * sizeof(uint32_t);
             hipError_t e = walk_grid<F>(lds_bytes, &resident);
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(wf_walk_kernel<F>, dim3(std::min(std::min(resident, pool.x), WF_MAX_WALK_GROUPS)), block, lds_bytes, stream, a);
