@@ -170,7 +170,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     kernel_ms, launches = 0.0, 0
-    tot = {k: 0 for k in ("segments", "bvh_node_steps", "bvh_sphere_tests", "bvh_rect_tests")}   # bvh_*: filled by the counting pass below
+    tot = {k: 0 for k in ("segments", "bvh_node_steps", "bvh_box_tests", "bvh_sphere_tests", "bvh_rect_tests")}   # bvh_*: filled by the counting pass below
     st = {}
     for _ in range(args.steps):
         step()
@@ -188,7 +188,7 @@ def main():
         ctx.frame_begin(W, H)
         ctx.render(min(count, 16), depth, spp_begin=begin, seed=0, jitter=jitter, kernel=st["kernel_used"] | rt.KERNEL_COUNT_WALKS)
         ct = ctx.stats()
-        for k in ("bvh_node_steps", "bvh_sphere_tests", "bvh_rect_tests"):
+        for k in ("bvh_node_steps", "bvh_box_tests", "bvh_sphere_tests", "bvh_rect_tests"):
             tot[k] = ct[k] * tot["segments"] // max(ct["segments"], 1)      # scaled to the timed steps' segments
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -199,7 +199,7 @@ def main():
         samples_per_step = W * H * total_spp
         value = samples_per_step * args.steps / elapsed / 1e6
         seg = max(tot["segments"], 1)
-        n_box, n_sph, n_rect = 2.0 * tot["bvh_node_steps"] / seg, tot["bvh_sphere_tests"] / seg, tot["bvh_rect_tests"] / seg
+        n_box, n_sph, n_rect = tot["bvh_box_tests"] / seg, tot["bvh_sphere_tests"] / seg, tot["bvh_rect_tests"] / seg
         per_segment = {"boxes": n_box, "spheres": n_sph + st["list_spheres"], "rects": n_rect + st["list_rects"],
                        "transforms": st["list_transforms"]}
         if scene_name == "cornell":

@@ -168,15 +168,19 @@ typedef struct mirt_stats {
     uint64_t lane_slots;   /* fused kernel: 64 x loop iterations summed over waves; segments / lane_slots =
                               share of lane-iterations that traced a segment (the rest idled in a wave whose
                               other lanes had longer paths) */
-    /* Algorithmic work of the hierarchy walks of the persistent kernel since mirt_frame_begin, counted per lane that
-     * took the step: interior nodes visited (two child boxes each), leaf spheres and leaf rects intersected (a cuboid
-     * is six). With the list_* fields — what one scan of the world's list entries tests, i.e. per segment — this
-     * prices a segment: 24 FLOP per box, 30 per sphere, 12 per rect, 15 per instance transform. */
+    /* Algorithmic work of the hierarchy walks since mirt_frame_begin, tallied by launches that carry
+     * MIRT_KERNEL_COUNT_WALKS, per lane that took the step: four-wide interior nodes visited (bvh_box_tests below
+     * holds their child boxes, two to four each), leaf spheres and leaf rects intersected (a cuboid is six). With
+     * the list_* fields — what one scan of the world's list entries tests, i.e. per segment — this prices a
+     * segment: 24 FLOP per box, 30 per sphere, 12 per rect, 15 per instance transform. */
     uint64_t bvh_node_steps, bvh_sphere_tests, bvh_rect_tests;
     uint32_t list_rects, list_spheres, list_transforms;
     uint32_t device_faults;    /* MIRT_FAULT_* bits the kernels raised since mirt_frame_begin; 0 in a correct run */
-    uint32_t bvh_deepest_leaf; /* level of the deepest leaf of the scene's hierarchies (root node = 1); the traversal
-                                  stack holds 32 entries and a leaf at level L needs L - 1 */
+    uint32_t bvh_deepest_leaf; /* level of the deepest leaf of the scene's binary hierarchies before they are
+                                  collapsed into four-wide nodes (root node = 1; the builder stops at level 33) */
+    uint32_t bvh_stack_entries; /* entries of the per-lane traversal stack the kernels are launched with: the exact
+                                  need of the scene's deepest four-wide hierarchy (at most 64, or the upload fails) */
+    uint64_t bvh_box_tests;    /* child boxes of the nodes counted in bvh_node_steps */
 } mirt_stats;
 #define MIRT_FAULT_STACK_OVERFLOW 1u /* a hierarchy walk found its traversal stack full and dropped a subtree */
 #define MIRT_FAULT_STALE_CHUNK 2u    /* a (pixel, sample chunk) work item of the persistent kernel was never stored */

@@ -514,10 +514,13 @@ MIRT_DEV void walk_push(Walk& w, uint32_t* stack, uint32_t stride, bool on, uint
     stack[w.sp * stride] = ref;
     w.sp += on ? 1u : 0u;
 }
-MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w, uint32_t* stack, uint32_t stride) {
+MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w, uint32_t* stack, uint32_t stride, uint32_t* wave_cost) {
     const float4* q = reinterpret_cast<const float4*>(s.bvh_nodes + w.ref);
     const float4 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3], z01 = q[4], z23 = q[5];
     const uint4 refs = reinterpret_cast<const uint4*>(q)[6];
+    // a counting launch (wave-uniform) tallies the child boxes the node really has: its first two, and the
+    // third and fourth where they exist
+    if (wave_cost) atomicAdd(wave_cost + 3, 2u + (refs.z != kWalkIdle ? 1u : 0u) + (refs.w != kWalkIdle ? 1u : 0u));
     const f32x2 cxy = {nc.x, nc.y}, czz = {nc.z, nc.z};
     const f32x2 rxy = {rinv.x, rinv.y}, rzz = {rinv.z, rinv.z};
 #define MIRT_CHILD(b, zlo, zhi, ref)                                                                              \
@@ -609,7 +612,7 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
         // descend through interior nodes until each of them holds a leaf (or is done), then all
         // intersect their leaves together, so the long leaf code runs with many lanes active.
         while (w.ref != kWalkIdle) {
-            while (ref_is_node(w.ref)) walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride);
+            while (ref_is_node(w.ref)) walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride, nullptr);
             if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, lr, w, stack, stride, tally);
         }
     }
@@ -637,7 +640,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
         if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w, lr);
         while (w.ref != kWalkIdle && steps < budget) {
             while (ref_is_node(w.ref) && steps < budget) {
-                walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride);
+                walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride, wave_cost);
                 ++steps;
                 if ((uint32_t)__popcll(__ballot(ref_is_node(w.ref))) < node_lanes) break;
             }

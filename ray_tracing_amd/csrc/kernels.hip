@@ -325,9 +325,9 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     Ray ray{v3(0.f, 0.f, 0.f), v3(0.f, 0.f, 1.f), 0.f};
     V3 thr = v3(1.f, 1.f, 1.f);
     uint32_t segments = 0, rounds = 0;  // of the whole wave (scalar registers)
-    __shared__ uint32_t s_walk_cost[(FT & F_BVH) ? (kBlock / 64) * 3 : 1];  // per wave: node steps, leaf spheres, leaf rects
-    uint32_t* const wave_words = s_walk_cost + ((FT & F_BVH) ? (threadIdx.x >> 6) * 3u : 0u);
-    if ((FT & F_BVH) && (threadIdx.x & 63u) == 0u) wave_words[0] = wave_words[1] = wave_words[2] = 0u;
+    __shared__ uint32_t s_walk_cost[(FT & F_BVH) ? (kBlock / 64) * 4 : 1];  // per wave: node steps, leaf spheres, leaf rects, child boxes
+    uint32_t* const wave_words = s_walk_cost + ((FT & F_BVH) ? (threadIdx.x >> 6) * 4u : 0u);
+    if ((FT & F_BVH) && (threadIdx.x & 63u) == 0u) wave_words[0] = wave_words[1] = wave_words[2] = wave_words[3] = 0u;
     uint32_t* const wave_cost = a.count_cost ? wave_words : nullptr;  // only a counting launch tallies (walk_some)
     MIRT_STATS(const long long t_birth = clock64(); long long ph0 = 0, ph1 = 0, ph2 = 0);
     Walk wk;               // the lane's walk of the hierarchies, kept from iteration to iteration
@@ -497,6 +497,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 atomicAdd(a.segment_counter + 2, (unsigned long long)wave_words[0]);
                 atomicAdd(a.segment_counter + 3, (unsigned long long)wave_words[1]);
                 atomicAdd(a.segment_counter + 4, (unsigned long long)wave_words[2]);
+                atomicAdd(a.segment_counter + 5, (unsigned long long)wave_words[3]);
             }
         }
     }

@@ -1007,6 +1007,8 @@ int mirt_get_stats(mirt_ctx* c, mirt_stats* out) {
     c->stats.bvh_node_steps = seg[2];
     c->stats.bvh_sphere_tests = seg[3];
     c->stats.bvh_rect_tests = seg[4];
+    c->stats.bvh_box_tests = seg[5];
+    c->stats.bvh_stack_entries = c->scene.stack_limit;
     c->stats.list_rects = c->list_rects;
     c->stats.list_spheres = c->list_spheres;
     c->stats.list_transforms = c->list_transforms;

@@ -10,10 +10,10 @@
 #include "wavefront.h"
 
 // Layout of the small device block every context owns (seg_counter): kCounters 64-bit statistics words (segments,
-// lane slots, hierarchy node steps, leaf sphere tests, leaf rect tests), the fault
+// lane slots, hierarchy node steps, leaf sphere tests, leaf rect tests, child boxes of the visited nodes), the fault
 // word the kernels OR FAULT_* bits into (byte kFaultOffset), and from byte kWorkCounterOffset the item counters of
 // the persistent render kernel, each in its own 128-byte line.
-constexpr int kCounters = 5;
+constexpr int kCounters = 6;
 constexpr size_t kFaultOffset = 64, kWorkCounterOffset = 128;
 
 struct mirt_ctx {

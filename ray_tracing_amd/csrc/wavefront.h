@@ -21,7 +21,7 @@ struct WfState {
     float4* q_d[2];  // direction.xyz, t of the closest hit so far
     uint2* q_h[2];   // bits of the hit primitive (int, -1 = none), slot
     uint32_t* ctl;   // control words, WF_CTL_*
-    unsigned long long* cost;  // per workgroup of the walk kernel: node steps, leaf spheres, leaf rects, - (summed at the end)
+    unsigned long long* cost;  // per workgroup of the walk kernel: node steps, leaf spheres, leaf rects, child boxes (summed at the end)
 };
 constexpr uint32_t WF_MAX_WALK_GROUPS = 4096;
 // Every queue is WF_LANES independent lanes, and so is the hand-out of work items: a read-modify-write on one

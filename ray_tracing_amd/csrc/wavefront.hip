@@ -230,10 +230,10 @@ __global__ __launch_bounds__(kWfBlock, 5) void wf_walk_kernel(WfArgs a) {
     // per-lane traversal stacks, [level][lane], only as many levels as the scene's hierarchies need
     // (a.r.scene.stack_limit, sized at launch): the LDS a workgroup takes decides how many are resident
     extern __shared__ uint32_t bvh_stack[];
-    __shared__ uint32_t s_walk_cost[(kWfBlock / 64) * 3];
+    __shared__ uint32_t s_walk_cost[(kWfBlock / 64) * 4];
     uint32_t* stack = bvh_stack + threadIdx.x;
-    uint32_t* const wave_words = s_walk_cost + (threadIdx.x >> 6) * 3u;
-    if ((threadIdx.x & 63u) == 0u) wave_words[0] = wave_words[1] = wave_words[2] = 0u;
+    uint32_t* const wave_words = s_walk_cost + (threadIdx.x >> 6) * 4u;
+    if ((threadIdx.x & 63u) == 0u) wave_words[0] = wave_words[1] = wave_words[2] = wave_words[3] = 0u;
     uint32_t* const wave_cost = a.r.count_cost ? wave_words : nullptr;  // only a counting launch tallies (walk_some)
     const uint32_t cur = a.round & 1u;
     const uint32_t refill = max(a.refill_lanes, 1u), run_len = max(a.fetch_run, 64u);
@@ -309,24 +309,24 @@ __global__ __launch_bounds__(kWfBlock, 5) void wf_walk_kernel(WfArgs a) {
     // what the walks cost goes to the workgroup's own words (added to the statistics when the render ends): the
     // thousands of waves of every round adding to three shared words was a quarter of a short round
     __syncthreads();
-    if (threadIdx.x < 3u && a.st.cost && a.r.count_cost) {
+    if (threadIdx.x < 4u && a.st.cost && a.r.count_cost) {
         unsigned long long s = 0;
-        for (uint32_t wv = 0; wv < kWfBlock / 64; ++wv) s += s_walk_cost[wv * 3u + threadIdx.x];
+        for (uint32_t wv = 0; wv < kWfBlock / 64; ++wv) s += s_walk_cost[wv * 4u + threadIdx.x];
         a.st.cost[(size_t)blockIdx.x * 4u + threadIdx.x] += s;
     }
 }
 
 __global__ __launch_bounds__(256) void wf_finish_kernel(WfArgs a) {
-    __shared__ unsigned long long part[256][3];
-    unsigned long long s[3] = {0, 0, 0};
+    __shared__ unsigned long long part[256][4];
+    unsigned long long s[4] = {0, 0, 0, 0};
     for (uint32_t b = threadIdx.x; b < WF_MAX_WALK_GROUPS; b += 256u)
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 4; ++j) {
             s[j] += a.st.cost[(size_t)b * 4u + j];
             a.st.cost[(size_t)b * 4u + j] = 0ull;
         }
-    for (int j = 0; j < 3; ++j) part[threadIdx.x][j] = s[j];
+    for (int j = 0; j < 4; ++j) part[threadIdx.x][j] = s[j];
     __syncthreads();
-    if (threadIdx.x < 3u && a.r.segment_counter) {
+    if (threadIdx.x < 4u && a.r.segment_counter) {
         unsigned long long t = 0;
         for (uint32_t i = 0; i < 256u; ++i) t += part[i][threadIdx.x];
         atomicAdd(a.r.segment_counter + 2 + threadIdx.x, t);

@@ -33,7 +33,7 @@ def run_case(case):
         ctx.frame_begin(W, H)
         ctx.render(spp, depth, seed=0, jitter=spp != 1, kernel=kern | rt.KERNEL_COUNT_WALKS)
         ct = ctx.stats()
-        row.append(f"{name} {best:.0f} ({st['kernel_launches']} launches; counted pass: {ct['bvh_node_steps'] / max(ct['segments'], 1):.1f} nodes + "
+        row.append(f"{name} {best:.0f} ({st['kernel_launches']} launches; counted pass: {ct['bvh_node_steps'] / max(ct['segments'], 1):.1f} nodes ({ct['bvh_box_tests'] / max(ct['segments'], 1):.1f} boxes) + "
                    f"{(ct['bvh_sphere_tests'] + ct['bvh_rect_tests']) / max(ct['segments'], 1):.2f} leaf tests per segment, {ct['samples'] / ct['kernel_ms'] / 1e3:.0f} Msamples/s)")
     print(f"{case:9s} {W}x{H} spp={spp} depth={depth} prims={sc.desc.n_prims} deepest leaf {st['bvh_deepest_leaf']} seg/sample={st['segments'] / st['samples']:.2f}  Msamples/s: "
           + ", ".join(row), flush=True)

@@ -133,9 +133,11 @@ def test_full_size_pass_properties(rt, oracle):
         ctx.render(1, 10, seed=6, jitter=False, kernel=k | rt.KERNEL_COUNT_WALKS)
         st = ctx.stats()
         assert (ctx.read_accum() == q[0]).all() and st["segments"] == q[1]["segments"]
-        tallies.append((st["bvh_node_steps"], st["bvh_sphere_tests"], st["bvh_rect_tests"]))
+        tallies.append((st["bvh_node_steps"], st["bvh_box_tests"], st["bvh_sphere_tests"], st["bvh_rect_tests"]))
         nodes = st["bvh_node_steps"] / st["segments"]
-        assert 10 < nodes < 120 and 0.5 * st["segments"] < st["bvh_sphere_tests"] < st["bvh_node_steps"] and st["bvh_rect_tests"] == 0
+        assert 5 < nodes < 60 and 0.5 * st["segments"] < st["bvh_sphere_tests"] < st["bvh_node_steps"] and st["bvh_rect_tests"] == 0
+        assert 2 * st["bvh_node_steps"] <= st["bvh_box_tests"] <= 4 * st["bvh_node_steps"]       # four-wide nodes hold 2-4 children
+        assert 0 < st["bvh_stack_entries"] <= 64
     assert tallies[0] == tallies[1]
     # a second pass on top: progressive refinement keeps adding
     ctx.frame_begin(W, H)

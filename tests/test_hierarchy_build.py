@@ -1,0 +1,25 @@
+"""Host-only check of the hierarchy builder (ray_tracing_amd/csrc/bvh_build.h): the binary SAH tree over the
+members of a BVHNode entry (aabb.rs:63-100 builds the reference's; any conservative tree returns the same closest
+hit) and its collapse into the four-wide nodes the kernels walk. tests/native/bvh4_check.cpp holds the checks
+(containment, every object in exactly one leaf, packed children, exact stack need); this test builds it with g++
+and runs it — no GPU, no library."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_four_wide_hierarchy_structure(tmp_path):
+    exe = tmp_path / "bvh4_check"
+    build = subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "native", "bvh4_check.cpp"), "-o", str(exe)],
+                           capture_output=True, text=True, timeout=300)
+    assert build.returncode == 0, build.stderr[-2000:]
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and run.stdout.strip().endswith("ok"), run.stdout[-3000:] + run.stderr[-1000:]
+    # the 485-sphere scene of scene.rs:46-52 is the size of the "cloud 485" case: its walks fit a 16-entry stack
+    line = [l for l in run.stdout.splitlines() if l.startswith("cloud 485")][0]
+    assert int(line.split()[-1]) <= 24
