@@ -281,6 +281,59 @@ def test_4k_frame_into_caller_owned_buffer(rt, oracle, earth):
     assert (got[:, :80, :3] == 0).all() and got[:, w // 2 - 100:w // 2 + 100, :3].sum() > 0
 
 
+def test_eight_sample_ranges_of_the_4k_configuration(rt, oracle, earth):
+    """The multi-GPU configuration at its full size on one device: Cornell 3840x2160, 16 384 samples per pixel,
+    split into eight ranges of 2 048 (what eight ranks render, renderer.rs:97-119 with the sample loop cut by
+    range). The eight accumulation buffers, added in rank order as the exchange step adds them, equal one render of
+    all 16 384 samples up to the association of the f32 sums; every pixel has its count; no device fault; and the
+    image, resampled to 96x54, agrees with the committed 16 384-sample mean image of the oracle (another seed) within
+    that image's own noise."""
+    import os
+    from conftest import ROOT
+    w, h, ranks, share, depth, seed = 3840, 2160, 8, 2048, 50, 11
+    _, ctx, _ = make(rt, oracle, earth, "cornell", w, h)
+    total = np.zeros((h, w, 4), np.float32)
+    segments = 0
+    for r in range(ranks):
+        ctx.frame_begin(w, h)
+        ctx.render(share, depth, spp_begin=r * share, seed=seed)
+        part = ctx.read_accum()
+        st = ctx.stats()
+        assert st["device_faults"] == 0 and (part[..., 3] == share).all()
+        segments += st["segments"]
+        total += part
+    ctx.frame_begin(w, h)
+    ctx.render(ranks * share, depth, seed=seed)
+    whole = ctx.read_accum()
+    st = ctx.stats()
+    assert st["device_faults"] == 0 and st["segments"] == segments          # the same paths either way
+    assert (whole[..., 3] == ranks * share).all() and (total[..., 3] == ranks * share).all()
+    np.testing.assert_allclose(total[..., :3], whole[..., :3], rtol=2e-5, atol=1e-3)
+    # against the oracle's committed mean image (96x54): pixel X of a W-wide frame covers u in [X, X + 1) / (W - 1)
+    # (renderer.rs:181-182), so the 4K image is resampled onto the small frame's footprints by exact overlap
+    # (the small frame's last column and row reach beyond u = 1, where the 4K frame has nothing: left out)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "converged_cornell.npz"))
+    mean, half = z["mean"], z["half_rmse"]
+    gh, gw = mean.shape[:2]
+
+    def overlap(n_small, n_big):
+        lo = np.arange(n_small)[:, None] * (n_big - 1) / (n_small - 1)     # footprint of small pixel X in big-pixel units
+        hi = lo + (n_big - 1) / (n_small - 1)
+        x = np.arange(n_big)[None, :]
+        wgt = np.clip(np.minimum(hi, x + 1) - np.maximum(lo, x), 0, None)
+        return (wgt / (hi - lo)).astype(np.float64)
+
+    img = (whole[..., :3] / whole[..., 3:4]).astype(np.float64)
+    rows = (overlap(gh, h) @ img.reshape(h, w * 3)).reshape(gh, w, 3)                     # two matrix products, rows first
+    small = np.einsum("Xx,Yxc->YXc", overlap(gw, w), rows)[:gh - 1, :gw - 1]
+    want = mean[:gh - 1, :gw - 1].astype(np.float64)
+    for c in range(3):
+        rmse = math.sqrt(((small[..., c] - want[..., c]) ** 2).mean())
+        assert rmse <= 1.0 * half[c] + 1e-4, (c, rmse, half[c])
+    lum = lambda im: (0.2126 * im[..., 0] + 0.7152 * im[..., 1] + 0.0722 * im[..., 2]).mean()
+    assert abs(lum(small) - lum(want)) <= 0.01 * lum(want), (lum(small), lum(want))
+
+
 def test_error_paths(rt):
     ctx = rt.Context(0)
     with pytest.raises(rt.MirtError, match="no scene"):
