@@ -20,6 +20,24 @@ def sanitise(c):
     return np.where(np.isinf(c), 1.0, c).astype(np.float32)
 
 
+def resample_onto(gh, gw, img):
+    """A large frame averaged over the pixel footprints of a small frame of the same view: pixel X of a W-wide frame
+    covers u in [X, X + 1) / (W - 1) (renderer.rs:181-182), so the weights are the exact overlaps of the footprints.
+    The small frame's last column and row reach beyond u = 1, where the large frame has nothing: they are left out
+    (the result is (gh - 1) x (gw - 1))."""
+    h, w = img.shape[:2]
+
+    def overlap(n_small, n_big):
+        lo = np.arange(n_small)[:, None] * (n_big - 1) / (n_small - 1)     # footprint of small pixel X in big-pixel units
+        hi = lo + (n_big - 1) / (n_small - 1)
+        x = np.arange(n_big)[None, :]
+        wgt = np.clip(np.minimum(hi, x + 1) - np.maximum(lo, x), 0, None)
+        return (wgt / (hi - lo)).astype(np.float64)
+
+    rows = (overlap(gh, h) @ img.astype(np.float64).reshape(h, w * 3)).reshape(gh, w, 3)   # two matrix products, rows first
+    return np.einsum("Xx,Yxc->YXc", overlap(gw, w), rows)[:gh - 1, :gw - 1]
+
+
 def make(rt, oracle, earth, name, w=W, h=H, **kw):
     e = earth if name in ("earth", "final") else None
     orc = oracle.OracleRenderer(name, w, h, earth_rgba=e, **kw)
@@ -309,29 +327,50 @@ def test_eight_sample_ranges_of_the_4k_configuration(rt, oracle, earth):
     assert st["device_faults"] == 0 and st["segments"] == segments          # the same paths either way
     assert (whole[..., 3] == ranks * share).all() and (total[..., 3] == ranks * share).all()
     np.testing.assert_allclose(total[..., :3], whole[..., :3], rtol=2e-5, atol=1e-3)
-    # against the oracle's committed mean image (96x54): pixel X of a W-wide frame covers u in [X, X + 1) / (W - 1)
-    # (renderer.rs:181-182), so the 4K image is resampled onto the small frame's footprints by exact overlap
-    # (the small frame's last column and row reach beyond u = 1, where the 4K frame has nothing: left out)
+    # against the oracle's committed mean image (96x54), resampled onto its pixel footprints
     z = np.load(os.path.join(ROOT, "tests", "golden", "converged_cornell.npz"))
     mean, half = z["mean"], z["half_rmse"]
     gh, gw = mean.shape[:2]
 
-    def overlap(n_small, n_big):
-        lo = np.arange(n_small)[:, None] * (n_big - 1) / (n_small - 1)     # footprint of small pixel X in big-pixel units
-        hi = lo + (n_big - 1) / (n_small - 1)
-        x = np.arange(n_big)[None, :]
-        wgt = np.clip(np.minimum(hi, x + 1) - np.maximum(lo, x), 0, None)
-        return (wgt / (hi - lo)).astype(np.float64)
-
-    img = (whole[..., :3] / whole[..., 3:4]).astype(np.float64)
-    rows = (overlap(gh, h) @ img.reshape(h, w * 3)).reshape(gh, w, 3)                     # two matrix products, rows first
-    small = np.einsum("Xx,Yxc->YXc", overlap(gw, w), rows)[:gh - 1, :gw - 1]
+    small = resample_onto(gh, gw, whole[..., :3] / whole[..., 3:4])
     want = mean[:gh - 1, :gw - 1].astype(np.float64)
     for c in range(3):
         rmse = math.sqrt(((small[..., c] - want[..., c]) ** 2).mean())
         assert rmse <= 1.0 * half[c] + 1e-4, (c, rmse, half[c])
     lum = lambda im: (0.2126 * im[..., 0] + 0.7152 * im[..., 1] + 0.0722 * im[..., 2]).mean()
     assert abs(lum(small) - lum(want)) <= 0.01 * lum(want), (lum(small), lum(want))
+
+
+@pytest.mark.parametrize("name,w,h,spp", [("random", 400, 225, 10), ("cornell", 1920, 1080, 1024), ("final", 1920, 1080, 256)])
+def test_benchmark_configurations_against_committed_means(rt, earth, name, w, h, spp):
+    """The single-GPU benchmark configurations at their full sizes (depth 50) against fixed data: the render,
+    resampled onto the footprints of tests/golden/converged_<scene>.npz (the oracle's mean image of N samples at
+    96x54 and the RMSE between the means of its two halves, half = 2 sigma / sqrt(N)). With n device samples per
+    small pixel the difference should have an RMSE of sigma sqrt(1/n + 1/N); the bar is 1.5 times that per channel
+    (1.0 half for n >> N, as in the test at the fixture's own size) and 1 % of mean luminance (2 % for the
+    10-sample configuration)."""
+    import os
+    from conftest import ROOT
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"converged_{name}.npz"))
+    mean, half, n_fix = z["mean"], z["half_rmse"], int(z["spp"])
+    gh, gw = mean.shape[:2]
+    ctx = rt.Context(0)
+    ctx.scene_upload(rt.select_scene(name, earth_rgba=earth if name == "final" else None))
+    ctx.camera_set(rt.Camera.select_camera(w / h, name))
+    ctx.frame_begin(w, h)
+    ctx.render(spp, int(z["depth"]), seed=777)
+    acc = ctx.read_accum()
+    st = ctx.stats()
+    assert st["device_faults"] == 0 and (acc[..., 3] == spp).all()
+    small = resample_onto(gh, gw, acc[..., :3] / acc[..., 3:4])
+    want = mean[:gh - 1, :gw - 1].astype(np.float64)
+    n_dev = spp * ((w - 1) / (gw - 1)) * ((h - 1) / (gh - 1))
+    for c in range(3):
+        sigma = half[c] * math.sqrt(n_fix) / 2
+        rmse = math.sqrt(((small[..., c] - want[..., c]) ** 2).mean())
+        assert rmse <= 1.5 * sigma * math.sqrt(1 / n_dev + 1 / n_fix) + 1e-4, (c, rmse, half[c], n_dev)
+    lum = lambda im: (0.2126 * im[..., 0] + 0.7152 * im[..., 1] + 0.0722 * im[..., 2]).mean()
+    assert abs(lum(small) - lum(want)) <= (0.02 if spp < 64 else 0.01) * lum(want), (lum(small), lum(want))
 
 
 def test_error_paths(rt):
