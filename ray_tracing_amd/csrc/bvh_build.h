@@ -1,5 +1,6 @@
-// Host-side flattening of the reference's pointer BVH (aabb.rs:63-135) into a linear array of
-// 64-byte two-child nodes. The tree SHAPE is this library's own (binned surface-area heuristic,
+// Host-side flattening of the reference's pointer BVH (aabb.rs:63-135): a linear array of 64-byte two-child
+// nodes first (BvhBuilder), then the 128-byte four-wide nodes the kernels walk (collapse_to_four, at the end of
+// this file). The tree SHAPE is this library's own (binned surface-area heuristic,
 // median fallback, bounded depth); the reference picks a random axis per node (aabb.rs:73), so no
 // particular shape is part of its behaviour — any conservative hierarchy returns the same closest
 // hit (ties between equal-t leaves aside, which the reference resolves by tree shape too).

@@ -411,7 +411,7 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
 }
 
 // ---------------------------------------------------------------------------------------------
-// flattened BVH (the device form of aabb.rs BVHNode): 64-byte nodes holding both child boxes,
+// flattened BVH (the device form of aabb.rs BVHNode): 128-byte nodes holding up to four child boxes,
 // leaves as runs of 32-byte primitive records, per-lane traversal stack in LDS.
 //
 // Traversal is written as a resumable walk: `Walk` holds everything a lane needs to continue

@@ -184,7 +184,7 @@ struct DevScene {
     uint32_t stack_limit;
 };
 enum : uint32_t {
-    FAULT_STACK_OVERFLOW = 1u,  // a walk had to push with its stack full: the far child was dropped
+    FAULT_STACK_OVERFLOW = 1u,  // a walk pushed beyond its stack: the children that did not fit were dropped
     FAULT_STALE_CHUNK = 2u,     // a (pixel, chunk) slot did not carry the stamp of its launch: its item was never stored
 };
 
