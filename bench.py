@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--random-num", type=int, dest="random_num")
     ap.add_argument("--scaling", choices=["weak", "strong"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-count-pass", action="store_true",
+                    help="skip the extra render that tallies the hierarchy walks (profiling runs: every launch of the trace is then a timed step or the warm-up)")
     args = ap.parse_args()
     cfg = dict(scaling="weak", random_num=11)
     cfg.update(CONFIGS[args.config])
@@ -184,7 +186,7 @@ def main():
     elapsed = time.perf_counter() - t0
     # one more pass, outside the timed region, that also tallies what the hierarchy walks cost (nodes visited, leaf
     # primitives intersected): the per-segment work the roofline figure is priced with
-    if rank == 0 and st.get("kernel_used") in (rt.KERNEL_QUEUE, rt.KERNEL_WAVEFRONT) and scene.desc.n_prims > 32:
+    if rank == 0 and not args.no_count_pass and st.get("kernel_used") in (rt.KERNEL_QUEUE, rt.KERNEL_WAVEFRONT) and scene.desc.n_prims > 32:
         ctx.frame_begin(W, H)
         ctx.render(min(count, 16), depth, spp_begin=begin, seed=0, jitter=jitter, kernel=st["kernel_used"] | rt.KERNEL_COUNT_WALKS)
         ct = ctx.stats()
