@@ -125,7 +125,9 @@ int mirt_comm_reduce(mirt_ctx* c, int root) {
     if (!c->comm) return mirt::ctx_fail(c, MIRT_ERR_STATE, "mirt_comm_reduce: mirt_comm_init_rank has not been called");
     if (root < 0 || root >= c->comm_ranks) return mirt::ctx_fail(c, MIRT_ERR_INVALID, "mirt_comm_reduce: root out of range");
     if (!c->accum) return mirt::ctx_fail(c, MIRT_ERR_STATE, "mirt_comm_reduce: no frame begun");
-    const Rccl* r = rccl(nullptr);
+    std::string why;
+    const Rccl* r = rccl(&why);
+    if (!r) return mirt::ctx_fail(c, MIRT_ERR_COMM, "mirt_comm_reduce: " + why);
     if (hipSetDevice(c->device) != hipSuccess) return mirt::ctx_fail(c, MIRT_ERR_HIP, "mirt_comm_reduce: hipSetDevice failed");
     const size_t count = (size_t)c->width * c->height * 4;
     // in place: the root's buffer receives the sum, the other ranks' buffers are only read
