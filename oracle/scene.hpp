@@ -243,6 +243,19 @@ struct SceneParams {
     ImageData earthmap;
 };
 
+// Two scenes the reference does not have, for known-answer tests only (tests/test_analytic_kats.py works their
+// expected radiance out by hand from material.rs:86-100, 194-199 and geo.rs:411-434): a lone fuzzy-metal sphere and a
+// lone ball of scattering medium, each under a uniform sky, so that every path's result is a product of albedos
+// times the sky, decided only by the draws.
+inline Scene kat_metal_sphere(const std::string& name) {
+    return Scene({}, {sphere(V3(0.f, 0.f, 0.f), 1.f, std::make_shared<Metal>(V3(0.8f, 0.6f, 0.4f), 0.5f))}, V3(0.5f, 0.75f, 1.f), name);
+}
+inline Scene kat_medium_ball(const std::string& name) {
+    auto glass = std::make_shared<Dielectric>(1.5f);   // the boundary's material is never used (geo.rs:393-435)
+    return Scene({}, {std::make_shared<ConstantMedium>(sphere(V3(0.f, 0.f, 0.f), 2.f, glass), 0.7f, std::make_shared<SolidColor>(V3(0.5f, 0.75f, 0.25f)))},
+                 V3(1.f, 0.5f, 0.25f), name);
+}
+
 // scene.rs:11-23
 inline Scene select_scene(const std::string& name, const SceneParams& p) {
     RngCtx& r = rng();
@@ -256,6 +269,8 @@ inline Scene select_scene(const std::string& name, const SceneParams& p) {
     if (name == "cornell") return cornell_box(name);
     if (name == "final") return final_scene(name, p.earthmap);
     if (name == "smoke") return cornell_smoke(name);
+    if (name == "kat_metal_sphere") return kat_metal_sphere(name);
+    if (name == "kat_medium_ball") return kat_medium_ball(name);
     return two_spheres(name);
 }
 
