@@ -244,7 +244,8 @@ inline uint32_t collapse_to_four(const std::vector<DevBvhNode>& nodes2, uint32_t
         DevBvhNode4 nd{};
         for (int i = 0; i < 4; ++i) {
             const bool have = i < k;
-            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            // a missing child is the point at +infinity, which no ray with a finite far bound reaches (walk_node)
+            float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {INFINITY, INFINITY, INFINITY};
             uint32_t ref = 0xffffffffu;
             if (have) {
                 for (int a = 0; a < 3; ++a) { lo[a] = kids[i].lo[a]; hi[a] = kids[i].hi[a]; }

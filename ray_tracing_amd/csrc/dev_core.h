@@ -499,12 +499,14 @@ MIRT_DEV void walk_pop(Walk& w, const uint32_t* stack, uint32_t stride) {
 // pair losers go on the stack first and the loser of the final last, so the second-nearest is usually popped next.
 // `stack` is this lane's column of an LDS array laid out [level][lane] (stride = blockDim.x words): pushes and pops
 // are conflict-free.
-// Entry distance of one child box, +inf when the ray misses it or the child does not exist.
-MIRT_DEV float child_entry(f32x2 lo_xy, f32x2 hi_xy, f32x2 z, uint32_t ref, float t_min, float closest) {
+// Entry distance of one child box, +inf when the ray misses it or the child does not exist. A missing child is
+// stored as the point (+inf, +inf, +inf): its plane distances are +inf on the axes the ray ascends and -inf on the
+// others, so its entry distance is +inf or its exit distance -inf, and with the far bound `closest` capped at a
+// finite value by the caller neither passes — no test of the reference is needed.
+MIRT_DEV float child_entry(f32x2 lo_xy, f32x2 hi_xy, f32x2 z, float t_min, float closest) {
     const float tn = fmaxf(fmaxf(fminf(lo_xy.x, hi_xy.x), fminf(lo_xy.y, hi_xy.y)), fmaxf(fminf(z.x, z.y), t_min));
     const float tf = fminf(fminf(fmaxf(lo_xy.x, hi_xy.x), fmaxf(lo_xy.y, hi_xy.y)), fminf(fmaxf(z.x, z.y), closest));
-    // (a missing child has no reference; its empty box would pass the test)
-    return ((tn <= tf * 1.000002f) & (ref != kWalkIdle)) ? tn : MIRT_INF;
+    return tn <= tf * 1.000002f ? tn : MIRT_INF;
 }
 // A conditional push without a branch: the reference is always stored at the top of the stack and the stack pointer
 // moves only when `on` is set (three pushes of a node step are three stores and three predicated increments
@@ -523,11 +525,13 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w,
     if (wave_cost) atomicAdd(wave_cost + 3, 2u + (refs.z != kWalkIdle ? 1u : 0u) + (refs.w != kWalkIdle ? 1u : 0u));
     const f32x2 cxy = {nc.x, nc.y}, czz = {nc.z, nc.z};
     const f32x2 rxy = {rinv.x, rinv.y}, rzz = {rinv.z, rinv.z};
-#define MIRT_CHILD(b, zlo, zhi, ref)                                                                              \
+    // (no hit lies beyond 1e38 for coordinates below 2^27 and the limited reciprocals of walk_ray)
+    const float far_bound = fminf(w.closest, 1e38f);
+#define MIRT_CHILD(b, zlo, zhi)                                                                                   \
     child_entry(__builtin_elementwise_fma(f32x2{b.x, b.y}, rxy, cxy), __builtin_elementwise_fma(f32x2{b.z, b.w}, rxy, cxy), \
-                __builtin_elementwise_fma(f32x2{zlo, zhi}, rzz, czz), ref, t_min, w.closest)
-    const float k0 = MIRT_CHILD(b0, z01.x, z01.y, refs.x), k1 = MIRT_CHILD(b1, z01.z, z01.w, refs.y);
-    const float k2 = MIRT_CHILD(b2, z23.x, z23.y, refs.z), k3 = MIRT_CHILD(b3, z23.z, z23.w, refs.w);
+                __builtin_elementwise_fma(f32x2{zlo, zhi}, rzz, czz), t_min, far_bound)
+    const float k0 = MIRT_CHILD(b0, z01.x, z01.y), k1 = MIRT_CHILD(b1, z01.z, z01.w);
+    const float k2 = MIRT_CHILD(b2, z23.x, z23.y), k3 = MIRT_CHILD(b3, z23.z, z23.w);
 #undef MIRT_CHILD
     const bool f01 = k0 <= k1, f23 = k2 <= k3;
     const float ka = f01 ? k0 : k1, la = f01 ? k1 : k0, kb = f23 ? k2 : k3, lb = f23 ? k3 : k2;

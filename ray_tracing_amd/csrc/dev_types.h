@@ -133,7 +133,7 @@ static_assert(sizeof(DevBvhNode) == 64, "DevBvhNode is four 16-byte quads");
 // its interior children replaced by THEIR children, so a walk takes one step, one dependent fetch, where the binary
 // tree took two or three. The box coordinates are grouped in the pairs the slab test consumes with packed two-float
 // arithmetic: xy[i] = (lo.x, lo.y, hi.x, hi.y) of child i, z01 = (lo.z, hi.z) of children 0 and 1, z23 of 2 and 3.
-// A missing child has an empty box and the reference 0xffffffff.
+// A missing child is the point (+inf, +inf, +inf) with the reference 0xffffffff: no ray with a finite far bound meets it.
 struct __attribute__((aligned(128))) DevBvhNode4 {
     float xy[4][4];
     float z01[4], z23[4];
