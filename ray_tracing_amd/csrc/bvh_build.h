@@ -257,9 +257,7 @@ inline uint32_t collapse_to_four(const std::vector<DevBvhNode>& nodes2, uint32_t
                     ref = n4;
                 }
             }
-            nd.xy[i][0] = lo[0]; nd.xy[i][1] = lo[1]; nd.xy[i][2] = hi[0]; nd.xy[i][3] = hi[1];
-            float* z = i < 2 ? nd.z01 : nd.z23;
-            z[(i & 1) * 2] = lo[2]; z[(i & 1) * 2 + 1] = hi[2];
+            for (int a = 0; a < 3; ++a) { nd.plane[2 * a][i] = lo[a]; nd.plane[2 * a + 1][i] = hi[a]; }
             nd.ref[i] = ref;
         }
         nd.pad[0] = (uint32_t)k;

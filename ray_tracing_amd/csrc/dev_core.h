@@ -11,8 +11,9 @@
 // one liberty is that the plane division uses a shared reciprocal plus one Newton step (result
 // correctly rounded except with probability ~2^-21), and the free path drawn inside a constant medium takes
 // its logarithm from v_log_f32 (the draw is random; t stays within 1e-6). Shading (sampling directions, pdfs,
-// throughput) uses the hardware approximations v_rcp / v_rsq / v_sqrt / v_sin / v_cos, which
-// perturb a sample by ~1e-6 relative and leave the estimator's expectation unchanged.
+// throughput) uses the hardware approximations v_rcp / v_rsq / v_sqrt / v_sin / v_cos and fused multiply-adds
+// written out by hand (fdot, fmadd, fcross, fma_), which perturb a sample by ~1e-6 relative and leave the
+// estimator's expectation unchanged.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "dev_types.h"
@@ -73,6 +74,18 @@ MIRT_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 MIRT_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 MIRT_DEV float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 MIRT_DEV V3 fast_normalize(V3 a) { return a * fast_rsq(norm_squared(a)); }
+// Fused forms for the shading code: a product that feeds a sum is one fused multiply-add, written out. (The
+// library is built with contraction off, so that the intersection code rounds every operation as the reference does;
+// letting the compiler contract the shading code instead of writing the fused operations out would fuse differently
+// from one kernel to the next, and the kernels could no longer be compared bit for bit.)
+MIRT_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+MIRT_DEV float fdot(V3 a, V3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+MIRT_DEV float fnorm_squared(V3 a) { return fdot(a, a); }
+MIRT_DEV V3 fmadd(V3 a, float t, V3 b) { return V3{fma_(t, b.x, a.x), fma_(t, b.y, a.y), fma_(t, b.z, a.z)}; }  // a + t * b
+MIRT_DEV V3 fcross(V3 a, V3 b) {
+    return V3{fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x))};
+}
+MIRT_DEV V3 fnormalize(V3 a) { return a * fast_rsq(fnorm_squared(a)); }
 // sin / cos of 2*pi*u for u in [0, 1): v_sin_f32 / v_cos_f32 take their argument in revolutions
 MIRT_DEV void sincos_2pi(float u, float& sn, float& cs) {
     sn = __builtin_amdgcn_sinf(u);
@@ -169,7 +182,7 @@ struct Rng {
         return unit_f32(w);
     }
     // rand_gen.rs:20-23
-    MIRT_DEV float range(float mn, float mx) { return mn + (mx - mn) * next(); }
+    MIRT_DEV float range(float mn, float mx) { return fma_(mx - mn, next(), mn); }
 };
 
 // rand_gen.rs:45-52 — rejection from the cube [-1,1)^3, three draws per trial.
@@ -179,7 +192,7 @@ MIRT_DEV V3 rand_in_unit_sphere(Rng& g) {
         float y = g.range(-1.f, 1.f);
         float z = g.range(-1.f, 1.f);
         V3 p = v3(x, y, z);
-        if (norm_squared(p) < 1.f) return p;
+        if (fnorm_squared(p) < 1.f) return p;
     }
 }
 // rand_gen.rs:70-78 — two draws per trial.
@@ -188,7 +201,7 @@ MIRT_DEV V3 rand_in_unit_disk(Rng& g) {
         float x = g.range(-1.f, 1.f);
         float y = g.range(-1.f, 1.f);
         V3 p = v3(x, y, 0.f);
-        if (norm_squared(p) >= 1.f) continue;
+        if (fma_(y, y, x * x) >= 1.f) continue;
         return p;
     }
 }
@@ -203,11 +216,11 @@ MIRT_DEV Onb onb_from_w(V3 w) {
     const bool ay = fabsf(w.x) > 0.9f;
     Onb o;
     o.v = v3(ay ? -w.z : 0.f, ay ? 0.f : w.z, ay ? w.x : -w.y);
-    o.u = cross(w, o.v);
+    o.u = fcross(w, o.v);
     o.w = w;
     return o;
 }
-MIRT_DEV V3 onb_local(const Onb& o, V3 c) { return (o.u * c.x + o.v * c.y) + o.w * c.z; }
+MIRT_DEV V3 onb_local(const Onb& o, V3 c) { return fmadd(fmadd(o.u * c.x, c.y, o.v), c.z, o.w); }
 
 // ---------------------------------------------------------------------------------------------
 // instances: Translation(RotationY(obj)) — geo.rs:306-315, 372-385
@@ -385,18 +398,96 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
     }
 }
 
-// ConstantMedium::hit (geo.rs:413-435).
+// The two crossings ConstantMedium::hit asks its boundary for (geo.rs:415-416: hit(-inf, inf), then
+// hit(t1 + 0.0001, inf)) when the boundary is one sphere: both calls of Sphere::hit (geo.rs:89-105) compute the same
+// discriminant and the same two roots and differ only in the range they accept, so the roots are computed once and
+// the two selections made on them — the same values bit for bit as two calls of sphere_hit_c.
+MIRT_DEV bool sphere_crossings(V3 center, float radius, const Ray& r, float& t1, float& t2) {
+    V3 oc = r.o - center;
+    float a = norm_squared(r.d);
+    float half_b = dot(oc, r.d);
+    float c = norm_squared(oc) - radius * radius;
+    float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.f) return false;
+    float sqrtd = sqrt_nr(discriminant);
+    float ra = fast_rcp(a);
+    const float root0 = div_nr(-half_b - sqrtd, a, ra), root1 = div_nr(-half_b + sqrtd, a, ra);
+    // first call, range (-inf, inf): only a NaN root is outside (accepting form, see sphere_hit_c)
+    const bool in0 = (root0 >= -MIRT_INF) & (root0 <= MIRT_INF), in1 = (root1 >= -MIRT_INF) & (root1 <= MIRT_INF);
+    if (!(in0 | in1)) return false;
+    t1 = in0 ? root0 : root1;
+    const float lim = t1 + 0.0001f;
+    const bool s0 = (root0 >= lim) & (root0 <= MIRT_INF), s1 = (root1 >= lim) & (root1 <= MIRT_INF);
+    if (!(s0 | s1)) return false;
+    t2 = s0 ? root0 : root1;
+    return true;
+}
+
+// The distances at which a ray meets two consecutive rects of one axis (a scan record of two), +inf for a rect it
+// misses: the arithmetic of rect_pair_hit without the range test. A NaN or infinite distance puts the hit point
+// outside every extent, so it comes out as +inf as well.
+template <uint32_t XI, uint32_t YI, uint32_t ZI>
+MIRT_DEV void rect_pair_distances(const float* f, V3 o, V3 d, V3 rinv, float& ta, float& tb) {
+    const float oz = comp(o, ZI), dz = comp(d, ZI), rz = comp(rinv, ZI);
+    const float ox = comp(o, XI), dx = comp(d, XI), oy = comp(o, YI), dy = comp(d, YI);
+    const f32x2 n = f32x2{f[0], f[1]} - oz;
+    const f32x2 q = n * rz;
+    const f32x2 e = __builtin_elementwise_fma(-q, (f32x2)dz, n);
+    const f32x2 t = __builtin_elementwise_fma(e, (f32x2)rz, q);  // div_nr on both halves
+    const f32x2 x = ox + t * dx;
+    const f32x2 y = oy + t * dy;
+    const bool ha = (x.x >= f[2]) & (x.x <= f[4]) & (y.x >= f[6]) & (y.x <= f[8]);
+    const bool hb = (x.y >= f[3]) & (x.y <= f[5]) & (y.y >= f[7]) & (y.y <= f[9]);
+    ta = ha ? t.x : MIRT_INF;
+    tb = hb ? t.y : MIRT_INF;
+}
+
+// The same two crossings for a boundary of three rect-pair records in one frame (a cuboid, geo.rs:245-289): the
+// six plane distances are computed once. The first scan of the list (range (-inf, inf), `t <= closest` narrowing as
+// it goes) ends with the smallest distance among the rects the ray meets; the second with the smallest that is
+// >= t1 + 0.0001 — two selections over the same six values the two scans would compute.
+MIRT_DEV bool cuboid_crossings(const DevScene& s, uint32_t first, const Ray& r, float& t1, float& t2) {
+    const DevScanRec r0 = load_const(s.scan + first);
+    const uint32_t inst = r0.code_inst >> 8;
+    const LRay lr = make_lray(inst ? to_local(load_const(s.instances + inst), r) : r);
+    float c[6];
+    rect_pair_distances<0, 1, 2>(r0.f, lr.r.o, lr.r.d, lr.rinv, c[0], c[1]);
+    const DevScanRec r1 = load_const(s.scan + first + 1);
+    rect_pair_distances<0, 2, 1>(r1.f, lr.r.o, lr.r.d, lr.rinv, c[2], c[3]);
+    const DevScanRec r2 = load_const(s.scan + first + 2);
+    rect_pair_distances<1, 2, 0>(r2.f, lr.r.o, lr.r.d, lr.rinv, c[4], c[5]);
+    t1 = fminf(fminf(fminf(c[0], c[1]), fminf(c[2], c[3])), fminf(c[4], c[5]));
+    if (!(t1 < MIRT_INF)) return false;
+    const float lim = t1 + 0.0001f;
+    t2 = MIRT_INF;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t2 = fminf(t2, c[i] >= lim ? c[i] : MIRT_INF);
+    return t2 < MIRT_INF;
+}
+
+// ConstantMedium::hit (geo.rs:413-435). The boundary's two crossings come from one evaluation of its primitives
+// where its shape allows (DevPrim::b[0] of a medium, set at upload): one static sphere, or the three rect pairs of a
+// cuboid; any other boundary list is scanned twice, as the reference does.
 template <uint32_t F>
 MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, float t_min, float t_max, const DrawKey& key,
                          float& t_out) {
     uint32_t bfirst = __float_as_uint(p.a[0]), bcount = __float_as_uint(p.a[1]);
+    const uint32_t shape = __float_as_uint(p.b[0]);  // wave-uniform, like the record itself
     float t1 = MIRT_INF, t2 = MIRT_INF;
-    int b = -1;
-    list_scan<F, false>(s, bfirst, bcount, r, -MIRT_INF, key, t1, b);
-    if (b < 0) return false;
-    b = -1;
-    list_scan<F, false>(s, bfirst, bcount, r, t1 + 0.0001f, key, t2, b);
-    if (b < 0) return false;
+    if ((F & F_SPHERE) && shape == MS_SPHERE) {
+        const DevScanRec rec = load_const(s.scan + bfirst);
+        const uint32_t inst = (F & F_INSTANCE) ? rec.code_inst >> 8 : 0u;
+        if (!sphere_crossings(v3(rec.f), rec.f[3], inst ? to_local(load_const(s.instances + inst), r) : r, t1, t2)) return false;
+    } else if ((F & F_RECT) && shape == MS_CUBOID) {
+        if (!cuboid_crossings(s, bfirst, r, t1, t2)) return false;
+    } else {
+        int b = -1;
+        list_scan<F, false>(s, bfirst, bcount, r, -MIRT_INF, key, t1, b);
+        if (b < 0) return false;
+        b = -1;
+        list_scan<F, false>(s, bfirst, bcount, r, t1 + 0.0001f, key, t2, b);
+        if (b < 0) return false;
+    }
     t1 = fmaxf(fmaxf(t_min, t1), 0.f);
     t2 = fminf(t_max, t2);
     if (t1 >= t2) return false;
@@ -488,24 +579,29 @@ MIRT_DEV void walk_pop(Walk& w, const uint32_t* stack, uint32_t stride) {
 
 // BVHNode::hit (aabb.rs:112-126) for one four-wide node, i.e. for a node of the reference's binary tree and its
 // interior children at once: test the (up to) four child boxes against [t_min, closest] (the slab test of
-// aabb.rs:43-60), continue with the nearest hit child and push the other hit ones. The 24 plane distances are twelve
-// packed fused multiply-adds, t = p * rinv + (-origin * rinv): half the issue time of packed subtract-then-multiply.
-// That form errs by 2^-24 (|origin * rinv| + |t|) instead of a few ulp of t; the boxes are stored padded by 2^-21 of
-// the hierarchy's largest coordinate, which covers the first term for origins within the scene, and the far bound is
-// widened by 16 ulp, which covers the second, the first for origins far outside (there |origin * rinv| is about
-// |t|) and the 1-ulp reciprocals — so the test stays conservative and the closest hit is unchanged.
+// aabb.rs:43-60), continue with the nearest hit child and push the other hit ones.
+// The node stores its coordinates by plane (DevBvhNode4): per axis the lane loads the quad of the planes its ray
+// enters through and the quad of those it leaves through — low and high bounds when the direction component is
+// positive, the other way round when it is negative; the choice is a 16-byte address offset taken from the sign of
+// the reciprocal, the same for every node of the walk. The 24 plane distances are twelve packed fused multiply-adds,
+// t = p * rinv + (-origin * rinv), and a child's entry and exit distances are one three-way max and one three-way
+// min of them: no min / max pairs to sort each slab's two distances.
+// The fused form errs by 2^-24 (|origin * rinv| + |t|) instead of a few ulp of t; the boxes are stored padded by
+// 2^-21 of the hierarchy's largest coordinate, which covers the first term for origins within the scene, and the far
+// bound is widened by 16 ulp, which covers the second, the first for origins far outside (there |origin * rinv| is
+// about |t|) and the 1-ulp reciprocals — so the test stays conservative and the closest hit is unchanged.
 // The nearest child comes out of a tournament of three comparisons on (entry distance, reference) pairs — (0, 1),
 // (2, 3), then the winners — whose losers are the references to push: no sorting network, no index arithmetic. The
 // pair losers go on the stack first and the loser of the final last, so the second-nearest is usually popped next.
 // `stack` is this lane's column of an LDS array laid out [level][lane] (stride = blockDim.x words): pushes and pops
 // are conflict-free.
-// Entry distance of one child box, +inf when the ray misses it or the child does not exist. A missing child is
-// stored as the point (+inf, +inf, +inf): its plane distances are +inf on the axes the ray ascends and -inf on the
-// others, so its entry distance is +inf or its exit distance -inf, and with the far bound `closest` capped at a
-// finite value by the caller neither passes — no test of the reference is needed.
-MIRT_DEV float child_entry(f32x2 lo_xy, f32x2 hi_xy, f32x2 z, float t_min, float closest) {
-    const float tn = fmaxf(fmaxf(fminf(lo_xy.x, hi_xy.x), fminf(lo_xy.y, hi_xy.y)), fmaxf(fminf(z.x, z.y), t_min));
-    const float tf = fminf(fminf(fmaxf(lo_xy.x, hi_xy.x), fmaxf(lo_xy.y, hi_xy.y)), fminf(fmaxf(z.x, z.y), closest));
+// Entry distance of one child box from its three entry and three exit distances, +inf when the ray misses it or the
+// child does not exist. A missing child is stored as the point (+inf, +inf, +inf): its distances are +inf on the
+// axes the ray ascends and -inf on the others, so its entry distance is +inf or its exit distance -inf, and with the
+// far bound `closest` capped at a finite value by the caller neither passes — no test of the reference is needed.
+MIRT_DEV float child_entry(float nx, float ny, float nz, float fx, float fy, float fz, float t_min, float closest) {
+    const float tn = fmaxf(fmaxf(fmaxf(nx, ny), nz), t_min);
+    const float tf = fminf(fminf(fminf(fx, fy), fz), closest);
     return tn <= tf * 1.000002f ? tn : MIRT_INF;
 }
 // A conditional push without a branch: the reference is always stored at the top of the stack and the stack pointer
@@ -517,22 +613,36 @@ MIRT_DEV void walk_push(Walk& w, uint32_t* stack, uint32_t stride, bool on, uint
     w.sp += on ? 1u : 0u;
 }
 MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w, uint32_t* stack, uint32_t stride, uint32_t* wave_cost) {
-    const float4* q = reinterpret_cast<const float4*>(s.bvh_nodes + w.ref);
-    const float4 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3], z01 = q[4], z23 = q[5];
-    const uint4 refs = reinterpret_cast<const uint4*>(q)[6];
+    // Byte offset of the entry quad inside an axis' pair of quads: 0 (low planes) where the ray ascends, 16 (high
+    // planes) where it descends. Invariant over the walk: the compiler keeps the three values across the node loop.
+    // (A reciprocal of -0 was limited to -2^100 by walk_ray: its sign picks the high planes, and the products say the
+    // same: the distances to the high planes are the smaller ones.)
+    const uint32_t sx = (__float_as_uint(rinv.x) >> 31) << 4, sy = (__float_as_uint(rinv.y) >> 31) << 4, sz = (__float_as_uint(rinv.z) >> 31) << 4;
+    const char* const nodes = reinterpret_cast<const char*>(s.bvh_nodes);
+    const uint32_t at = w.ref << 7;  // byte offset of the node: the upload refuses more than 2^25 nodes
+    const uint32_t ax = at | sx, ay = (at | sy) + 32u, az = (at | sz) + 64u;
+    const float4 px = *reinterpret_cast<const float4*>(nodes + ax), qx = *reinterpret_cast<const float4*>(nodes + (ax ^ 16u));
+    const float4 py = *reinterpret_cast<const float4*>(nodes + ay), qy = *reinterpret_cast<const float4*>(nodes + (ay ^ 16u));
+    const float4 pz = *reinterpret_cast<const float4*>(nodes + az), qz = *reinterpret_cast<const float4*>(nodes + (az ^ 16u));
+    const uint4 refs = *reinterpret_cast<const uint4*>(nodes + at + 96u);
     // a counting launch (wave-uniform) tallies the child boxes the node really has: its first two, and the
     // third and fourth where they exist
     if (wave_cost) atomicAdd(wave_cost + 3, 2u + (refs.z != kWalkIdle ? 1u : 0u) + (refs.w != kWalkIdle ? 1u : 0u));
-    const f32x2 cxy = {nc.x, nc.y}, czz = {nc.z, nc.z};
-    const f32x2 rxy = {rinv.x, rinv.y}, rzz = {rinv.z, rinv.z};
+    const f32x2 rx = {rinv.x, rinv.x}, ry = {rinv.y, rinv.y}, rz = {rinv.z, rinv.z};
+    const f32x2 cx = {nc.x, nc.x}, cy = {nc.y, nc.y}, cz = {nc.z, nc.z};
+    // entry (n) and exit (f) distances of children (0, 1) and (2, 3) on each axis
+    const f32x2 nx01 = __builtin_elementwise_fma(f32x2{px.x, px.y}, rx, cx), nx23 = __builtin_elementwise_fma(f32x2{px.z, px.w}, rx, cx);
+    const f32x2 fx01 = __builtin_elementwise_fma(f32x2{qx.x, qx.y}, rx, cx), fx23 = __builtin_elementwise_fma(f32x2{qx.z, qx.w}, rx, cx);
+    const f32x2 ny01 = __builtin_elementwise_fma(f32x2{py.x, py.y}, ry, cy), ny23 = __builtin_elementwise_fma(f32x2{py.z, py.w}, ry, cy);
+    const f32x2 fy01 = __builtin_elementwise_fma(f32x2{qy.x, qy.y}, ry, cy), fy23 = __builtin_elementwise_fma(f32x2{qy.z, qy.w}, ry, cy);
+    const f32x2 nz01 = __builtin_elementwise_fma(f32x2{pz.x, pz.y}, rz, cz), nz23 = __builtin_elementwise_fma(f32x2{pz.z, pz.w}, rz, cz);
+    const f32x2 fz01 = __builtin_elementwise_fma(f32x2{qz.x, qz.y}, rz, cz), fz23 = __builtin_elementwise_fma(f32x2{qz.z, qz.w}, rz, cz);
     // (no hit lies beyond 1e38 for coordinates below 2^27 and the limited reciprocals of walk_ray)
     const float far_bound = fminf(w.closest, 1e38f);
-#define MIRT_CHILD(b, zlo, zhi)                                                                                   \
-    child_entry(__builtin_elementwise_fma(f32x2{b.x, b.y}, rxy, cxy), __builtin_elementwise_fma(f32x2{b.z, b.w}, rxy, cxy), \
-                __builtin_elementwise_fma(f32x2{zlo, zhi}, rzz, czz), t_min, far_bound)
-    const float k0 = MIRT_CHILD(b0, z01.x, z01.y), k1 = MIRT_CHILD(b1, z01.z, z01.w);
-    const float k2 = MIRT_CHILD(b2, z23.x, z23.y), k3 = MIRT_CHILD(b3, z23.z, z23.w);
-#undef MIRT_CHILD
+    const float k0 = child_entry(nx01.x, ny01.x, nz01.x, fx01.x, fy01.x, fz01.x, t_min, far_bound);
+    const float k1 = child_entry(nx01.y, ny01.y, nz01.y, fx01.y, fy01.y, fz01.y, t_min, far_bound);
+    const float k2 = child_entry(nx23.x, ny23.x, nz23.x, fx23.x, fy23.x, fz23.x, t_min, far_bound);
+    const float k3 = child_entry(nx23.y, ny23.y, nz23.y, fx23.y, fy23.y, fz23.y, t_min, far_bound);
     const bool f01 = k0 <= k1, f23 = k2 <= k3;
     const float ka = f01 ? k0 : k1, la = f01 ? k1 : k0, kb = f23 ? k2 : k3, lb = f23 ? k3 : k2;
     const uint32_t ra = f01 ? refs.x : refs.y, pa = f01 ? refs.y : refs.x, rb = f23 ? refs.z : refs.w, pb = f23 ? refs.w : refs.z;
@@ -738,8 +848,8 @@ MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim,
             h.u = phi / (2.f * kPi);
             h.v = theta / kPi;
         }
-        V3 on = fast_normalize(outward);
-        front = dot(lr.d, on) < 0.f;
+        V3 on = fnormalize(outward);
+        front = fdot(lr.d, on) < 0.f;
         nl = select(front, on, -on);
     } else {
         // geo.rs:205-211
@@ -781,26 +891,31 @@ MIRT_DEV float perlin_noise(const DevPerlin& pl, V3 p) {
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float x = pc[a] - fl[a];
-        uvw[a] = x * x * (3.f - 2.f * x);
+        uvw[a] = x * x * fma_(-2.f, x, 3.f);
     }
     const float wu[2] = {1.f - uvw[0], uvw[0]}, wv[2] = {1.f - uvw[1], uvw[1]}, ww[2] = {1.f - uvw[2], uvw[2]};
     const float du[2] = {uvw[0], uvw[0] - 1.f}, dv[2] = {uvw[1], uvw[1] - 1.f}, dw[2] = {uvw[2], uvw[2] - 1.f};
     const int px[2] = {pl.perm[0][ix & 0xff], pl.perm[0][(ix + 1) & 0xff]};
     const int py[2] = {pl.perm[1][iy & 0xff], pl.perm[1][(iy + 1) & 0xff]};
     const int pz[2] = {pl.perm[2][iz & 0xff], pl.perm[2][(iz + 1) & 0xff]};
+    // four gradients at a time, the arithmetic after them: four loads in flight instead of four round trips (all
+    // eight at once cost more registers than the hierarchy variants of the render kernel have to spare)
     float accm = 0.f;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+        float4 grad[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) grad[c] = *reinterpret_cast<const float4*>(pl.grad[px[i] ^ py[c >> 1] ^ pz[c & 1]]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const float puv = wu[i] * wv[j];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const int ind = px[i] ^ py[j] ^ pz[k];
-                const float4 c = *reinterpret_cast<const float4*>(pl.grad[ind]);
-                accm += ((c.x * du[i] + c.y * dv[j]) + c.z * dw[k]) * (puv * ww[k]);
+                const float4 c = grad[j * 2 + k];
+                accm = fma_(fma_(c.z, dw[k], fma_(c.y, dv[j], c.x * du[i])), puv * ww[k], accm);
             }
         }
+    }
     return accm;
 }
 // perlin.rs:65-71
@@ -808,7 +923,7 @@ MIRT_DEV float perlin_turb(const DevPerlin& pl, V3 p) {
     float accum = 0.f, weight = 1.f;
     V3 tp = p;
     for (int i = 0; i < 7; ++i) {
-        accum = accum + weight * perlin_noise(pl, tp);
+        accum = fma_(weight, perlin_noise(pl, tp), accum);
         weight = 0.5f * weight;
         tp = 2.f * tp;
     }
@@ -829,7 +944,7 @@ MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 
     }
     if ((F & F_TEX_NOISE) && kind == TK_NOISE) {
         // texture.rs:64-68
-        float g = 0.5f * (1.f + fast_sin(t.c1[3] * p.z + 10.f * perlin_turb(s.perlins[t.perlin], p)));
+        float g = fma_(0.5f, fast_sin(fma_(t.c1[3], p.z, 10.f * perlin_turb(s.perlins[t.perlin], p))), 0.5f);
         return v3(g, g, g);
     }
     if ((F & F_TEX_IMAGE) && kind == TK_IMAGE) {
@@ -858,11 +973,11 @@ MIRT_DEV float light_pdf_one(const DevPrim& p, V3 origin, V3 v, V3 vinv) {
         uint32_t xi, yi, zi;
         axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
         float t = (p.a[0] - comp(origin, zi)) * comp(vinv, zi);
-        float x = comp(origin, xi) + t * comp(v, xi);
-        float y = comp(origin, yi) + t * comp(v, yi);
+        float x = fma_(t, comp(v, xi), comp(origin, xi));
+        float y = fma_(t, comp(v, yi), comp(origin, yi));
         bool h = (t >= 0.001f) & (x >= p.a[1]) & (x <= p.a[2]) & (y >= p.a[3]) & (y <= p.b[0]);
         float area = fabsf((p.a[2] - p.a[1]) * (p.b[0] - p.a[3]));
-        float dis_squared = t * t * norm_squared(v);
+        float dis_squared = t * t * fnorm_squared(v);
         float cosine = fabsf(comp(v, zi));
         return h ? dis_squared * fast_rcp(cosine * area) : 0.f;
     }
@@ -871,16 +986,16 @@ MIRT_DEV float light_pdf_one(const DevPrim& p, V3 origin, V3 v, V3 vinv) {
         V3 c = sphere_center<F>(p, 0.f);
         float radius = p.a[3];
         V3 oc = origin - c;
-        float a = norm_squared(v);
-        float half_b = dot(oc, v);
-        float cc = norm_squared(oc) - radius * radius;
-        float disc = half_b * half_b - a * cc;
+        float a = fnorm_squared(v);
+        float half_b = fdot(oc, v);
+        float cc = fma_(-radius, radius, fnorm_squared(oc));
+        float disc = fma_(half_b, half_b, -(a * cc));
         float sqrtd = fast_sqrt(disc);
         float ra = fast_rcp(a);
         float root0 = (-half_b - sqrtd) * ra, root1 = (-half_b + sqrtd) * ra;
         bool h = (disc >= 0.f) & ((root0 >= 0.001f) | (root1 >= 0.001f));
         V3 c0 = v3(p.a[0], p.a[1], p.a[2]);
-        float cos_theta_max = fast_sqrt(1.f - radius * radius * fast_rcp(norm_squared(c0 - origin)));
+        float cos_theta_max = fast_sqrt(fma_(-(radius * radius), fast_rcp(fnorm_squared(c0 - origin)), 1.f));
         float solid_angle = 2.f * kPi * (1.f - cos_theta_max);
         return h ? fast_rcp(solid_angle) : 0.f;  // NaN when the origin is inside the sphere (geo.rs:138)
     }
@@ -909,7 +1024,7 @@ MIRT_DEV V3 axis_draw_direction(const AxisDraw& a) {
 }
 // rand_gen.rs:80-90 around `normal` — r2 in [0, 0.9): z >= sqrt(0.1).
 MIRT_DEV AxisDraw cosine_draw(V3 normal, float xi1, float xi2) {
-    float r2 = 0.f + (0.9f - 0.f) * xi2;
+    float r2 = 0.9f * xi2;  // rand_gen.rs:20-23 with min 0: 0 + (0.9 - 0) * xi
     return AxisDraw{normal, xi1, fast_sqrt(r2), fast_sqrt(1.f - r2)};
 }
 
@@ -922,19 +1037,19 @@ MIRT_DEV bool light_draw(const DevPrim& p, V3 origin, float xi1, float xi2, V3& 
     if ((F & F_RECT) && kind == PK_RECT) {
         uint32_t xi, yi, zi;
         axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
-        float a = p.a[1] + (p.a[2] - p.a[1]) * xi1;
-        float b = p.a[3] + (p.b[0] - p.a[3]) * xi2;
+        float a = fma_(p.a[2] - p.a[1], xi1, p.a[1]);
+        float b = fma_(p.b[0] - p.a[3], xi2, p.a[3]);
         float k = p.b[1];
         V3 pt = v3(xi == 0 ? a : (yi == 0 ? b : k), xi == 1 ? a : (yi == 1 ? b : k), xi == 2 ? a : (yi == 2 ? b : k));
-        dir = fast_normalize(pt - origin);
+        dir = fnormalize(pt - origin);
         return false;
     }
     if ((F & F_SPHERE) && kind == PK_SPHERE) {
         V3 c0 = v3(p.a[0], p.a[1], p.a[2]);
         V3 direction = c0 - origin;
-        float d = norm_squared(direction);
-        float z = 1.f + xi2 * (fast_sqrt(1.f - p.a[3] * p.a[3] * fast_rcp(d)) - 1.f);
-        ad = AxisDraw{direction * fast_rsq(d), xi1, fast_sqrt(1.f - z * z), z};
+        float d = fnorm_squared(direction);
+        float z = fma_(xi2, fast_sqrt(fma_(-(p.a[3] * p.a[3]), fast_rcp(d), 1.f)) - 1.f, 1.f);
+        ad = AxisDraw{direction * fast_rsq(d), xi1, fast_sqrt(fma_(-z, z, 1.f)), z};
         return true;
     }
     dir = v3(1.f, 0.f, 0.f);  // ray.rs:41-43
@@ -967,39 +1082,38 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, co
     uint32_t mk = m.mat_kind;
     if ((F & F_MAT_METAL) && mk == MK_METAL) {
         // material.rs:86-100
-        V3 reflected = ray.d - (2.f * dot(h.n, ray.d)) * h.n;
-        V3 sd = reflected + m.param * rand_in_unit_sphere(g);
-        if (!(dot(h.n, sd) > 0.f)) return false;
+        V3 reflected = fmadd(ray.d, -2.f * fdot(h.n, ray.d), h.n);
+        V3 sd = fmadd(reflected, m.param, rand_in_unit_sphere(g));
+        if (!(fdot(h.n, sd) > 0.f)) return false;
         ray.o = h.p;
-        ray.d = fast_normalize(sd);
+        ray.d = fnormalize(sd);
         thr = cmul(thr, v3(m.color));
         return true;
     }
     if ((F & F_MAT_DIELECTRIC) && mk == MK_DIELECTRIC) {
         // material.rs:129-151
         float ratio = h.front ? fast_rcp(m.param) : m.param;
-        float cos_theta = fminf(-dot(ray.d, h.n), 1.f);
-        float sin_theta = fast_sqrt(1.f - cos_theta * cos_theta);
+        float cos_theta = fminf(-fdot(ray.d, h.n), 1.f);
+        float sin_theta = fast_sqrt(fma_(-cos_theta, cos_theta, 1.f));
         bool reflect = ratio * sin_theta > 1.f;
         if (!reflect) {
             float r0 = (1.f - ratio) * fast_rcp(1.f + ratio);
             r0 = r0 * r0;
             float x = 1.f - cos_theta;
             float x2 = x * x;
-            float refl = r0 + (1.f - r0) * (x2 * x2 * x);  // material.rs:121-125
+            float refl = fma_(1.f - r0, x2 * x2 * x, r0);  // material.rs:121-125
             reflect = refl > g.next();                      // drawn only when refraction is possible
         }
-        V3 perp = ratio * (ray.d + cos_theta * h.n);        // material.rs:114-119
-        V3 par = (-fast_sqrt(fabsf(1.f - norm_squared(perp)))) * h.n;
-        V3 refr = fast_normalize(perp + par);
-        V3 refl_d = ray.d - (2.f * dot(h.n, ray.d)) * h.n;  // material.rs:75-77
+        V3 perp = ratio * fmadd(ray.d, cos_theta, h.n);     // material.rs:114-119
+        V3 refr = fnormalize(fmadd(perp, -fast_sqrt(fabsf(1.f - fnorm_squared(perp))), h.n));  // perp + par
+        V3 refl_d = fmadd(ray.d, -2.f * fdot(h.n, ray.d), h.n);  // material.rs:75-77
         ray.o = h.p;
         ray.d = select(reflect, refl_d, refr);
         return true;                                        // attenuation 1, divisor 1
     }
     if ((F & F_MAT_ISOTROPIC) && mk == MK_ISOTROPIC) {
         // material.rs:194-199
-        V3 dir = fast_normalize(rand_in_unit_sphere(g));
+        V3 dir = fnormalize(rand_in_unit_sphere(g));
         V3 att = shade_color<F>(s, m, h);
         ray.o = h.p;
         ray.d = dir;
@@ -1013,7 +1127,7 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, co
     if (s.n_lights == 0) {
         float a = g.next(), b = g.next();
         dir = axis_draw_direction(cosine_draw(h.n, a, b));          // pdf.rs:30-32
-        float c = dot(dir, h.n);
+        float c = fdot(dir, h.n);
         pdf_val = c <= 0.f ? 0.0001f : c * (1.f / kPi);             // pdf.rs:25-28
     } else {
         float sel = g.next();
@@ -1028,12 +1142,12 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, co
             around_axis = light_draw<F>(tb.light_prims[li], h.p, b, c, dir, ad);
         }
         if (around_axis) dir = axis_draw_direction(ad);
-        float c = dot(dir, h.n);
+        float c = fdot(dir, h.n);
         float p0 = c <= 0.f ? 0.0001f : c * (1.f / kPi);
         float p1 = lights_pdf<F>(s, h.p, dir);
-        pdf_val = 0.5f * p0 + 0.5f * p1;                            // pdf.rs:73-75
+        pdf_val = fma_(0.5f, p0, 0.5f * p1);                        // pdf.rs:73-75
     }
-    float cosine = fmaxf(dot(dir, h.n), 0.0001f);                   // renderer.rs:219
+    float cosine = fmaxf(fdot(dir, h.n), 0.0001f);                  // renderer.rs:219
     // renderer.rs:221,227: attenuation / (pdf_val / cosine * 2 pi)
     float w = cosine * fast_rcp(pdf_val * (2.f * kPi));
     ray.o = h.p;
@@ -1056,17 +1170,17 @@ MIRT_DEV Ray camera_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t w
     float s = div_nr((float)x + xo, wm1, fast_rcp(wm1));
     float t = div_nr((float)y + yo, hm1, fast_rcp(hm1));
     Ray r;
-    V3 target = ((v3(cam.llc) + s * v3(cam.horizontal)) + t * v3(cam.vertical)) - v3(cam.origin);
+    V3 target = fmadd(fmadd(v3(cam.llc), s, v3(cam.horizontal)), t, v3(cam.vertical)) - v3(cam.origin);
     if (PINHOLE) {
         r.o = v3(cam.origin);
-        r.d = fast_normalize(target);
+        r.d = fnormalize(target);
         r.time = cam.time0;
         return r;
     }
     V3 rd = cam.lens_radius * rand_in_unit_disk(g);
-    V3 offset = v3(cam.u) * rd.x + v3(cam.v) * rd.y;
+    V3 offset = fmadd(v3(cam.u) * rd.x, rd.y, v3(cam.v));
     r.o = v3(cam.origin) + offset;
-    r.d = fast_normalize(target - offset);
+    r.d = fnormalize(target - offset);
     r.time = g.range(cam.time0, cam.time1);
     return r;
 }

@@ -16,10 +16,15 @@ enum : uint32_t {
     PM_MOVING = 1u << 5,
 };
 
+// Shape of a medium's boundary list, found at upload: one static sphere, or the three rect-pair scan records (XY, XZ,
+// YZ, one instance) of a cuboid, let ConstantMedium::hit take both crossings from one evaluation of the boundary.
+enum : uint32_t { MS_LIST = 0, MS_SPHERE = 1, MS_CUBOID = 2 };
+
 struct __attribute__((aligned(16))) DevPrim {
     // sphere: a = (center0.xyz, radius)        b = (center1.xyz, time0)     c0 = time1
     // rect:   a = (k, lo0, hi0, lo1)           b = (hi1, k_mid, 0, 0)
     // medium: a = (bits first boundary scan record, bits record count, neg_inv_density, bits medium_index)
+    //         b[0] = bits MS_* (shape of the boundary list)
     float a[4];
     float b[4];
     float c0;
@@ -131,12 +136,14 @@ static_assert(sizeof(DevBvhNode) == 64, "DevBvhNode is four 16-byte quads");
 
 // 128-byte node (one cache line, seven 16-byte loads) holding the boxes of up to four children: a binary node with
 // its interior children replaced by THEIR children, so a walk takes one step, one dependent fetch, where the binary
-// tree took two or three. The box coordinates are grouped in the pairs the slab test consumes with packed two-float
-// arithmetic: xy[i] = (lo.x, lo.y, hi.x, hi.y) of child i, z01 = (lo.z, hi.z) of children 0 and 1, z23 of 2 and 3.
+// tree took two or three. The coordinates are stored by plane: plane[2 a] = the low bounds of the four children on
+// axis a, plane[2 a + 1] = their high bounds. A lane reads, per axis, the quad its ray enters through and the quad it
+// leaves through — which is which depends only on the sign of the ray's direction on that axis, so it is an address
+// offset (0 or 16 bytes) fixed for the whole walk — and has the near and far distances of all four children without
+// a single min / max to tell them apart.
 // A missing child is the point (+inf, +inf, +inf) with the reference 0xffffffff: no ray with a finite far bound meets it.
 struct __attribute__((aligned(128))) DevBvhNode4 {
-    float xy[4][4];
-    float z01[4], z23[4];
+    float plane[6][4];
     uint32_t ref[4];
     uint32_t pad[4];
 };

@@ -318,6 +318,14 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
         make_scan(p.boundary_first, p.boundary_count, &rf, &rc);
         std::memcpy(&prims[i].a[0], &rf, 4);
         std::memcpy(&prims[i].a[1], &rc, 4);
+        // boundary shapes whose two crossings come from one evaluation (medium_hit in dev_core.h)
+        uint32_t shape = MS_LIST;
+        auto code_of = [&](uint32_t k) { return scan[rf + k].code_inst & 0xffu; };
+        if (rc == 1 && code_of(0) == SC_SPHERE) shape = MS_SPHERE;
+        if (rc == 3 && code_of(0) == SC_RECT2_XY && code_of(1) == SC_RECT2_XZ && code_of(2) == SC_RECT2_YZ &&
+            (scan[rf].code_inst >> 8) == (scan[rf + 1].code_inst >> 8) && (scan[rf].code_inst >> 8) == (scan[rf + 2].code_inst >> 8))
+            shape = MS_CUBOID;
+        std::memcpy(&prims[i].b[0], &shape, 4);
     }
     // ---- materials / textures
     for (uint32_t i = 0; i < d->n_materials; ++i) {
@@ -498,6 +506,7 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     }
     // leaf records of the hierarchies, in tree order (a leaf reference holds a 27-bit record index)
     if (slots.size() >= (1u << 27) - 1u) return bad("too many hierarchy members");
+    if (nodes.size() >= (1u << 25)) return bad("too many hierarchy nodes (a walk addresses a node by a 32-bit byte offset: at most 2^25 nodes of 128 bytes)");
     std::vector<DevLeafRec> leaves(slots.size());
     for (size_t i = 0; i < slots.size(); ++i) {
         if (!slot_is_cuboid[i]) {

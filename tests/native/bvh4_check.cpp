@@ -33,8 +33,7 @@ static uint32_t check_node(const std::vector<DevBvhNode4>& nodes, uint32_t n, co
     Box all{{INFINITY, INFINITY, INFINITY}, {-INFINITY, -INFINITY, -INFINITY}};
     uint32_t below = 0;
     for (uint32_t i = 0; i < 4; ++i) {
-        const float* z = i < 2 ? nd.z01 : nd.z23;
-        Box stored{{nd.xy[i][0], nd.xy[i][1], z[(i & 1) * 2]}, {nd.xy[i][2], nd.xy[i][3], z[(i & 1) * 2 + 1]}};
+        Box stored{{nd.plane[0][i], nd.plane[2][i], nd.plane[4][i]}, {nd.plane[1][i], nd.plane[3][i], nd.plane[5][i]}};
         if (i >= k) {
             CHECK(nd.ref[i] == 0xffffffffu, "slot %u beyond the child count holds a reference", i);
             continue;
