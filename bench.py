@@ -9,10 +9,20 @@ resolve, with scene and camera already resident on the GPU.
 With N > 1 there is one process per GPU. Started by torch.distributed.run (RANK / WORLD_SIZE in the
 environment) this file is a rank; started plainly with --gpus N it launches the N ranks itself, as child
 processes, before anything in this process touches a GPU. Every rank renders the whole frame for its own range
-of samples (weak: `spp` samples per rank, N*spp per pixel in total; strong: `spp` split over the ranks), the
-float4 accumulation buffers are summed onto rank 0 by the library's RCCL reduce (ncclReduce over xGMI, on the
-render stream), and rank 0 resolves. torch.distributed (gloo) is the control plane only: it carries the RCCL id
-and the barriers. Rank 0 prints ONE JSON line.
+of samples, the float4 accumulation buffers are summed onto rank 0 by the library's RCCL reduce (ncclReduce over
+xGMI, on the render stream), and rank 0 resolves. torch.distributed (gloo) is the control plane only: it carries
+the RCCL id and the barriers. Rank 0 prints ONE JSON line; for N > 1 it carries `per_rank`: the render time of
+every rank (HIP events), the slowest and fastest, and the reduce time on the root, so a poor scaling curve can be
+read (unbalanced renders against a slow exchange). The run fails if the communicator does not span all N ranks.
+
+Two splits:
+  weak (default, so that N = 1 is the headline number):  python bench.py --gpus N            `spp` samples per rank,
+                                                         N * spp per pixel in total
+  strong (the 8-GPU configuration of the metric):        python bench.py --gpus N --config 4  16 384 spp of a
+                                                         3840x2160 Cornell frame split over the N ranks
+The reduce over two or more GPUs has not run on hardware yet (the boxes this was built on have one GPU; on one
+GPU RCCL refuses a second rank): it is covered by world-size 2, 3 and 8 gloo tests of the same split on the CPU and
+by the library's RCCL path at world size 1.
 
 Other configurations of the metric's family (parity-tested, reported for their rooflines):
   1  random 400x225, 10 spp, depth 50            3  final 1920x1080, 256 spp, depth 50
@@ -153,7 +163,8 @@ def main():
 
     def step():
         ctx.frame_begin(W, H)
-        ctx.render(count, depth, spp_begin=begin, seed=0, jitter=jitter)
+        if count > 0:                       # (a strong split over more ranks than samples leaves some with none)
+            ctx.render(count, depth, spp_begin=begin, seed=0, jitter=jitter)
         if world > 1:
             ctx.comm_reduce(0)              # RCCL sum of the float4 buffers onto rank 0, behind the render on its stream
         if rank == 0:
@@ -171,7 +182,7 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms, launches = 0.0, 0
+    kernel_ms, launches, reduce_ms = 0.0, 0, 0.0
     tot = {k: 0 for k in ("segments", "bvh_node_steps", "bvh_box_tests", "bvh_sphere_tests", "bvh_rect_tests")}   # bvh_*: filled by the counting pass below
     st = {}
     for _ in range(args.steps):
@@ -179,6 +190,7 @@ def main():
         st = ctx.stats()                    # HIP-event time of this step's render launches, on the render stream
         kernel_ms += st["kernel_ms"]
         launches += st["kernel_launches"]
+        reduce_ms += st["reduce_ms"]
         tot["segments"] += st["segments"]
         if st["device_faults"]:
             raise SystemExit(f"device faults {st['device_faults']}")
@@ -192,10 +204,22 @@ def main():
         ct = ctx.stats()
         for k in ("bvh_node_steps", "bvh_box_tests", "bvh_sphere_tests", "bvh_rect_tests"):
             tot[k] = ct[k] * tot["segments"] // max(ct["segments"], 1)      # scaled to the timed steps' segments
+    per_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        mine = {"rank": rank, "device": device, "spp": count, "render_ms_per_step": kernel_ms / args.steps,
+                "reduce_ms_per_step": reduce_ms / args.steps, "rccl_ranks": ctx.comm_ranks()}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        bad = [r for r in everyone if r["rccl_ranks"] != world]
+        if bad:
+            raise SystemExit(f"the RCCL communicator spans {bad[0]['rccl_ranks']} ranks on rank {bad[0]['rank']}, not {world}")
+        renders = [r["render_ms_per_step"] for r in everyone]
+        per_rank = {"render_ms_max": max(renders), "render_ms_min": min(renders), "reduce_ms_root": everyone[0]["reduce_ms_per_step"],
+                    "note": "reduce_ms is measured on the root's stream and includes its wait for the slowest rank's render",
+                    "ranks": everyone}
 
     if rank == 0:
         samples_per_step = W * H * total_spp
@@ -210,13 +234,13 @@ def main():
             flop_per_segment = (FLOP_BOX * per_segment["boxes"] + FLOP_SPHERE * per_segment["spheres"] + FLOP_RECT * per_segment["rects"]
                                 + FLOP_TRANSFORM * per_segment["transforms"] + FLOP_SHADE)
         achieved = flop_per_segment * tot["segments"] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        traffic, traffic_src = None, None
+        traffic, traffic_src, prof = None, None, {}
         try:
             with open(TRAFFIC_FILE) as f:
-                entry = json.load(f).get(f"{scene_name} {W}x{H} {count}spp depth{depth}")
-            if entry:
-                traffic, traffic_src = entry["bytes_per_launch"], entry["profile"]
-        except (OSError, ValueError):
+                prof = json.load(f).get(f"{scene_name} {W}x{H} {count}spp depth{depth}") or {}
+            if prof:
+                traffic, traffic_src = prof["bytes_per_launch"], prof["profile"]
+        except (OSError, ValueError, KeyError):
             pass
         out = {
             "metric": "Msamples/sec at 1920x1080 Cornell box; % of FP32-VALU/HBM roofline",
@@ -228,20 +252,23 @@ def main():
                                    + (f", random_num {cfg['random_num']} ({scene.desc.n_prims} spheres)" if cfg["random_num"] != 11 else ""),
                        "config_id": args.config, "samples_per_step": samples_per_step,
                        "parallelism": f"spp-range x{world}" + (" + RCCL reduce" if world > 1 else ""), "rccl_ranks": ctx.comm_ranks()},
-            # compute-bound, not HBM-bound: of the two roofline categories this is the arithmetic one. A path tracer
-            # has no matrix products, so the arithmetic runs on the vector ALUs; for f32 the vector peak and the
-            # dense MFMA peak of the MI355X are the same 157.3 TFLOP/s.
-            "roofline": {"bound": "mfma", "bound_note": "f32 vector-ALU issue bound (no matrix ops in this path); f32 VALU peak = f32 MFMA peak",
+            # compute-bound on the vector ALUs (a path tracer has no matrix products: no MFMA), not HBM-bound
+            "roofline": {"bound": "valu", "bound_note": "f32 vector-ALU issue bound; peak = packed f32 FMA rate of the vector ALUs",
                          "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "frac_of_unpacked_fma_rate": achieved / UNPACKED_FP32_TFLOPS,
                          "traffic": traffic, "traffic_unit": "bytes per launch (PMC, separate run)", "traffic_profile": traffic_src,
+                         # from the committed profile of this same command (rocprofv3 --pmc passes, code object notes)
+                         "lanes_per_valu": prof.get("lanes_per_valu"), "valu_issue_clk": prof.get("valu_issue_clk"),
+                         "vgpr": prof.get("vgpr"), "scratch_bytes": prof.get("scratch_bytes"),
                          "kernel": "render_queue_kernel" if st.get("kernel_used") == rt.KERNEL_QUEUE else "render_fused_kernel",
                          "avg_launch_ms": kernel_ms / max(launches, 1),
                          "segments_per_sample": tot["segments"] / (W * H * count * args.steps),
                          "gsegments_per_s": tot["segments"] / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
                          "flop_per_segment": flop_per_segment, "tests_per_segment": per_segment},
         }
+        if per_rank:
+            out["per_rank"] = per_rank
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene_name, W, H, depth, cfg["random_num"])
         print(json.dumps(out), flush=True)

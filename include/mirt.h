@@ -181,6 +181,9 @@ typedef struct mirt_stats {
     uint32_t bvh_stack_entries; /* entries of the per-lane traversal stack the kernels are launched with: the exact
                                   need of the scene's deepest four-wide hierarchy (at most 64, or the upload fails) */
     uint64_t bvh_box_tests;    /* child boxes of the nodes counted in bvh_node_steps */
+    double reduce_ms;          /* GPU time of this context's part in the last mirt_comm_reduce / mirt_reduce since
+                                  mirt_frame_begin, HIP events on the render stream (it includes the wait for the
+                                  slowest rank's render); 0 when none ran */
 } mirt_stats;
 #define MIRT_FAULT_STACK_OVERFLOW 1u /* a hierarchy walk found its traversal stack full and dropped a subtree */
 #define MIRT_FAULT_STALE_CHUNK 2u    /* a (pixel, sample chunk) work item of the persistent kernel was never stored */
@@ -212,12 +215,15 @@ int mirt_render(mirt_ctx* ctx, const mirt_render_params* p);
 /* mirt_render for callers that cannot allocate device memory — code under HIP graph capture, tight serving loops,
  * harnesses that forbid hipMalloc. It has no counterpart in the reference. It renders the same samples with the
  * persistent kernel (kernel = MIRT_KERNEL_AUTO or MIRT_KERNEL_QUEUE), but the kernel's item counters and chunk sums
- * live in a static device array of the library (256 MiB + 4 KiB, held on every GPU the library runs on until the
- * process ends) instead of buffers grown on demand, and the call allocates and frees nothing. Frames of more than
- * MIRT_STATIC_MAX_PIXELS pixels (two chunk images must fit) or 65535 in one dimension are rejected. A frame that
- * fits sixteen chunk images (up to 1 Mi pixels) gets the sums of mirt_render bit for bit; a larger one gets fewer,
- * longer chunks, i.e. another grouping of the same float additions. All calls on one GPU share that GPU's array:
- * calls that overlap on one GPU (two contexts, two streams) race; one at a time is the contract. The frame
+ * live in a static device array of the library (64 MiB + 4 KiB, held on every GPU the process uses the library on
+ * until the process ends, whether or not this entry point is ever called) instead of buffers grown on demand, and
+ * the call allocates and frees nothing. Frames of more than MIRT_STATIC_MAX_PIXELS pixels or 65535 in one dimension
+ * are rejected. A frame that fits sixteen chunk images in the array (up to 256 Ki pixels) gets the sums of
+ * mirt_render bit for bit; a larger one gets fewer, longer chunks (1920x1080: two), and one whose two chunk images
+ * do not fit is rendered with whole pixels as work items — other groupings of the same float additions, and a
+ * longer tail of the launch. All calls on one GPU share that GPU's array: calls that overlap on one GPU (two
+ * contexts, two streams) race; one at a time is the contract. A captured HIP graph replays the stamp of its
+ * capture, so the report of never-stored work items (MIRT_FAULT_STALE_CHUNK) is blind across replays. The frame
  * (mirt_frame_begin, itself allocation-free with a caller-owned accum_device), scene and camera are set up before. */
 #define MIRT_STATIC_MAX_PIXELS 8388608u
 int mirt_render_static(mirt_ctx* ctx, const mirt_render_params* p);

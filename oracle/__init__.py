@@ -35,6 +35,8 @@ def lib():
         L.orc_num_leaf_ids.argtypes = [C.c_void_p]
         L.orc_num_lights.argtypes = [C.c_void_p]
         L.orc_camera_get.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_set_total_spp.argtypes = [C.c_void_p, C.c_uint32]
+        L.orc_set_total_spp.restype = None
         L.orc_render_sums.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                       C.c_void_p, C.c_void_p]
         L.orc_draw.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_size_t]
@@ -126,8 +128,10 @@ class OracleRenderer:
         lib().orc_camera_get(self._h, _p(out))
         return out
 
-    def render_sums(self, spp_count, max_depth, seed=0, spp_begin=0, threads=None):
-        """Returns (sums[H,W,3] with row 0 = image bottom, counters[4])."""
+    def render_sums(self, spp_count, max_depth, seed=0, spp_begin=0, threads=None, total_spp=0):
+        """Returns (sums[H,W,3] with row 0 = image bottom, counters[4]). total_spp: samples per pixel of the whole
+        render when this call renders a range of them (a one-sample range of a longer render still jitters)."""
+        lib().orc_set_total_spp(self._h, int(total_spp))
         threads = threads or min(os.cpu_count() or 1, 16)
         sums = np.zeros((self.height, self.width, 3), dtype=np.float32)
         cnt = np.zeros(4, dtype=np.uint64)

@@ -68,6 +68,10 @@ void orc_camera_get(void* hv, float* out21) {
 
 // Sum of sanitised samples [spp_begin, spp_begin + spp_count) per pixel; sums[(y*W + x)*3 + c],
 // y = 0 at the image bottom. counters4 = {segments, sphere tests, rect tests, aabb tests}.
+// Samples per pixel of the whole render of which later orc_render_sums calls render ranges (decides the pixel
+// jitter, renderer.rs:175); 0 = every call stands for itself.
+void orc_set_total_spp(void* hv, uint32_t spp_total) { static_cast<Handle*>(hv)->r->spp_total = spp_total; }
+
 int orc_render_sums(void* hv, uint32_t spp_begin, uint32_t spp_count, uint32_t max_depth, uint32_t seed, int threads,
                     float* sums, uint64_t* counters4) {
     try {

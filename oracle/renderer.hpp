@@ -21,6 +21,7 @@ struct Renderer {
     // Oracle-only controls
     uint32_t seed = 0;        // Philox counter word 3
     uint32_t spp_begin = 0;   // global index of the first sample (for sample-range splits)
+    uint32_t spp_total = 0;   // samples per pixel of the whole render when this call renders a range of them (0: multisample)
     int threads = 1;
     Counters totals;
 
@@ -35,7 +36,7 @@ struct Renderer {
     // renderer.rs:174-184 — divides by (width-1)/(height-1); no jitter when multisample == 1.
     void cal_norm_coords(uint32_t x, uint32_t y, float out[2]) const {
         float x_offset = 0.f, y_offset = 0.f;
-        if (multisample != 1) {
+        if ((spp_total ? spp_total : multisample) != 1) {  // a range of a longer render jitters as the whole does
             x_offset = get_rand();
             y_offset = get_rand();
         }

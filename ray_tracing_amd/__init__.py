@@ -53,7 +53,7 @@ class mirt_stats(C.Structure):
                 ("bvh_node_steps", C.c_uint64), ("bvh_sphere_tests", C.c_uint64), ("bvh_rect_tests", C.c_uint64),
                 ("list_rects", C.c_uint32), ("list_spheres", C.c_uint32), ("list_transforms", C.c_uint32),
                 ("device_faults", C.c_uint32), ("bvh_deepest_leaf", C.c_uint32),
-                ("bvh_stack_entries", C.c_uint32), ("bvh_box_tests", C.c_uint64)]
+                ("bvh_stack_entries", C.c_uint32), ("bvh_box_tests", C.c_uint64), ("reduce_ms", C.c_double)]
 
 
 class mirt_prim(C.Structure):
@@ -343,7 +343,7 @@ class Context:
                 "kernel_launches": s.kernel_launches, "kernel_used": s.kernel_used, "lane_slots": s.lane_slots,
                 "device_faults": s.device_faults, "bvh_deepest_leaf": s.bvh_deepest_leaf,
                 "bvh_node_steps": s.bvh_node_steps, "bvh_sphere_tests": s.bvh_sphere_tests, "bvh_rect_tests": s.bvh_rect_tests,
-                "bvh_box_tests": s.bvh_box_tests, "bvh_stack_entries": s.bvh_stack_entries,
+                "bvh_box_tests": s.bvh_box_tests, "bvh_stack_entries": s.bvh_stack_entries, "reduce_ms": s.reduce_ms,
                 "list_rects": s.list_rects, "list_spheres": s.list_spheres, "list_transforms": s.list_transforms}
 
     # ---- the exchange step of the sample-range split (RCCL sum of the accumulation buffers onto `root`)

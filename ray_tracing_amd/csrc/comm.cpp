@@ -131,8 +131,10 @@ int mirt_comm_reduce(mirt_ctx* c, int root) {
     if (hipSetDevice(c->device) != hipSuccess) return mirt::ctx_fail(c, MIRT_ERR_HIP, "mirt_comm_reduce: hipSetDevice failed");
     const size_t count = (size_t)c->width * c->height * 4;
     // in place: the root's buffer receives the sum, the other ranks' buffers are only read
+    (void)hipEventRecord(c->ev_r0, c->stream);
     ncclResult_t rc = r->Reduce(c->accum, c->accum, count, ncclFloat, ncclSum, root, static_cast<ncclComm_t>(c->comm), c->stream);
     if (rc != ncclSuccess) return comm_fail(c, r, "ncclReduce", rc);
+    c->reduce_timed = hipEventRecord(c->ev_r1, c->stream) == hipSuccess;
     return MIRT_OK;
 }
 
@@ -177,6 +179,10 @@ int mirt_reduce(mirt_ctx** ctxs, int n, int root) {
         }
     }
     const size_t count = (size_t)c0->width * c0->height * 4;
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(ctxs[i]->device);
+        (void)hipEventRecord(ctxs[i]->ev_r0, ctxs[i]->stream);
+    }
     ncclResult_t rc = r->GroupStart();
     if (rc != ncclSuccess) return comm_fail(c0, r, "ncclGroupStart", rc);
     ncclResult_t first_bad = ncclSuccess;
@@ -187,6 +193,10 @@ int mirt_reduce(mirt_ctx** ctxs, int n, int root) {
     rc = r->GroupEnd();
     if (first_bad != ncclSuccess) return comm_fail(c0, r, "ncclReduce", first_bad);
     if (rc != ncclSuccess) return comm_fail(c0, r, "ncclGroupEnd", rc);
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(ctxs[i]->device);
+        ctxs[i]->reduce_timed = hipEventRecord(ctxs[i]->ev_r1, ctxs[i]->stream) == hipSuccess;
+    }
     return MIRT_OK;
 }
 

@@ -747,7 +747,16 @@ template <uint32_t F>
 MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t min_lanes,
                         uint32_t node_lanes, uint32_t* stack, uint32_t stride, uint32_t& steps, uint32_t* wave_cost) {
     steps = 0;
-    uint32_t tally = 0;
+    uint32_t tally = 0, tallied_steps = 0;
+    // (a counting launch only) the lane's tally goes to the wave's words: at the end of the turn, and whenever its
+    // leaf-step field is a sixteenth full — a turn without a step budget can outlast the fields otherwise
+    auto flush_tally = [&]() {
+        atomicAdd(wave_cost + 0, (steps - tallied_steps) - (tally & 1023u));
+        atomicAdd(wave_cost + 1, (tally >> 10) & 2047u);
+        atomicAdd(wave_cost + 2, tally >> 21);
+        tallied_steps = steps;
+        tally = 0;
+    };
     LRay lr = make_lray(r);
     if (w.ref != kWalkIdle) lr = walk_ray<F>(s, r, w.next - 1u);  // resuming inside hierarchy w.next - 1
     for (;;) {
@@ -762,6 +771,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
                 walk_leaf<F>(s, t_min, lr, w, stack, stride, tally);
                 tally += kTallyLeafStep;
                 ++steps;
+                if (wave_cost && (tally & 1023u) >= 64u) flush_tally();
             }
             // few lanes left walking: they stop here too and go on next iteration, together with the walks
             // the other lanes will have started by then
@@ -769,11 +779,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
         }
         if (w.ref != kWalkIdle || w.next >= n) break;  // out of budget, or every hierarchy walked
     }
-    if (wave_cost) {  // wave-uniform: a counting launch
-        atomicAdd(wave_cost + 0, steps - (tally & 1023u));
-        atomicAdd(wave_cost + 1, (tally >> 10) & 2047u);
-        atomicAdd(wave_cost + 2, tally >> 21);
-    }
+    if (wave_cost) flush_tally();  // wave-uniform: a counting launch
     return w.ref == kWalkIdle;
 }
 

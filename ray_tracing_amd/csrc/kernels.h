@@ -29,7 +29,7 @@ struct RenderArgs {
     // slots up counts a chunk's samples only when the stamp is there, so an item that was never stored shows as a
     // short sample count (and FAULT_STALE_CHUNK) instead of passing off an earlier launch's sums. Never 0.
     uint32_t stamp;
-    uint32_t debug_drop_pixel;  // tests: the item of this pixel's first chunk is not stored (0xffffffff: none)
+    uint32_t debug_drop_pixel;  // test build (-DMIRT_DEBUG_HOOKS) only: the item of this pixel's first chunk is not stored (0xffffffff: none)
     uint32_t count_cost;        // tally the hierarchy walks' node steps and leaf tests into the statistics (slower: not for timed launches)
 };
 enum : uint32_t { LOOP_AUTO = 0, LOOP_FUSED = 1, LOOP_QUEUE = 2 };
@@ -42,8 +42,12 @@ bool render_uses_queue(const RenderArgs& a);
 // device the library runs on holds its own copy at its own address; static_scratch_address() returns the copy of the
 // CURRENT device (looked up once per device with hipGetSymbolAddress and kept).
 constexpr size_t kStaticPartialOffset = 4096;
-constexpr size_t kStaticPartialBytes = 256u << 20;  // two chunk images of 8 Mi pixels, or eight of a 1920x1080 frame
+constexpr size_t kStaticPartialBytes = 64u << 20;  // two chunk images of a 1920x1080 frame (33.2 MB each); a frame whose two images do not fit renders unchunked
 hipError_t static_scratch_address(void** out);
+// Stamp for the next launch that fills the CURRENT device's static scratch (RenderArgs::stamp): counted per device,
+// because every context on a device shares that device's array — a per-context count would let two contexts issue
+// the same stamp and take each other's slots for their own. Never 0.
+uint32_t static_scratch_next_stamp();
 
 struct RayBatchArgs {
     DevScene scene;

@@ -371,10 +371,18 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     // straight to the accumulation buffer; otherwise to the item's own slot, and reduce_chunks_kernel adds
     // the slots of a pixel in chunk order — no floating-point atomics, so the result does not depend on
     // which lane rendered what, or when.
-    const uint32_t stamp = a.stamp, drop_pixel = a.debug_drop_pixel;
+    const uint32_t stamp = a.stamp;
+#ifdef MIRT_DEBUG_HOOKS
+    const uint32_t drop_pixel = a.debug_drop_pixel;
+#else
+    constexpr uint32_t drop_pixel = 0xffffffffu;  // the hook exists only in the test build of the library
+#endif
     auto flush_pixel = [&pixel, &sample_end, &acc, accum, partial, spp_count, n_chunks, n_pixels, spp_begin, chunk_spp, stamp, drop_pixel]() {
         const uint32_t chunk = (sample_end - 1u - spp_begin) / chunk_spp;
+#ifdef MIRT_DEBUG_HOOKS
         if (pixel == drop_pixel && chunk == 0u) return;
+#endif
+        (void)drop_pixel;
         if (n_chunks == 1u) {
             float4 v = accum[pixel];
             v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += spp_count;
@@ -722,23 +730,35 @@ extern "C" void mirt_debug_walk_hist(unsigned long long* out) {
 // memory is reached through the per-device address below, never through the name.
 static __device__ __align__(256) unsigned char scratch[kStaticPartialOffset + kStaticPartialBytes];
 
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_of_device[kMaxDevices] = {};
+uint32_t g_scratch_stamp[kMaxDevices] = {};  // stamp of the last launch that filled the device's scratch
+}  // namespace
+
 hipError_t static_scratch_address(void** out) {
-    constexpr int kMaxDevices = 64;
-    static std::mutex mu;
-    static void* per_device[kMaxDevices] = {};
     *out = nullptr;
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!per_device[device]) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_of_device[device]) {
         void* p = nullptr;
         if ((e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch))) != hipSuccess) return e;
-        per_device[device] = p;
+        g_scratch_of_device[device] = p;
     }
-    *out = per_device[device];
+    *out = g_scratch_of_device[device];
     return hipSuccess;
+}
+
+uint32_t static_scratch_next_stamp() {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= kMaxDevices) return 1u;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (++g_scratch_stamp[device] == 0) g_scratch_stamp[device] = 1;
+    return g_scratch_stamp[device];
 }
 
 bool render_uses_queue(const RenderArgs& a) {

@@ -166,12 +166,19 @@ int mirt_create(int device, mirt_ctx** out) {
     if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreate(&c->ev0)) != hipSuccess) return bail("hipEventCreate", e);
     if ((e = hipEventCreate(&c->ev1)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev_r0)) != hipSuccess) return bail("hipEventCreate", e);
+    if ((e = hipEventCreate(&c->ev_r1)) != hipSuccess) return bail("hipEventCreate", e);
     // kCounters statistics words, then (from byte 128) the item counters of the persistent render kernel
     static_assert(kCounters * sizeof(unsigned long long) <= kFaultOffset && kFaultOffset + 4 <= kWorkCounterOffset, "block layout");
     if ((e = hipMalloc(reinterpret_cast<void**>(&c->seg_counter), kWorkCounterOffset + kWorkCounterBytes)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemset(c->seg_counter, 0, kWorkCounterOffset + kWorkCounterBytes)) != hipSuccess) return bail("hipMemset", e);
     // this device's copy of the static scratch array (mirt_render_static renders without allocating)
-    if ((e = static_scratch_address(&c->static_scratch)) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
+    // (a device on which the static scratch cannot be found still renders through mirt_render; mirt_render_static
+    // reports the missing scratch when it is called)
+    if (static_scratch_address(&c->static_scratch) != hipSuccess) {
+        c->static_scratch = nullptr;
+        (void)hipGetLastError();
+    }
     *out = c;
     return MIRT_OK;
 }
@@ -190,6 +197,8 @@ void mirt_destroy(mirt_ctx* c) {
     if (c->wf_counts_host) (void)hipHostFree(c->wf_counts_host);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_r0) (void)hipEventDestroy(c->ev_r0);
+    if (c->ev_r1) (void)hipEventDestroy(c->ev_r1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -578,8 +587,11 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     for (int a = 0; a < 3; ++a) s.background[a] = d->background[a];
     s.fault = fault_word(c);
     s.stack_limit = stack_need;   // what the deepest walk can need: the kernels' LDS stacks are launched this deep
-    // (tests lower the limit to see the overflow report of walk_node)
-    if (const char* e = std::getenv("MIRT_DEBUG_STACK_LIMIT")) s.stack_limit = (uint32_t)std::min<long>(std::max<long>(std::atol(e), 1), (long)stack_need);
+    // (the test build of the library lets a test lower the limit to see the overflow report of walk_node)
+#ifdef MIRT_DEBUG_HOOKS
+    static const long stack_env = [] { const char* e = std::getenv("MIRT_DEBUG_STACK_LIMIT"); return e ? std::atol(e) : -1l; }();
+    if (stack_env >= 0) s.stack_limit = (uint32_t)std::min<long>(std::max<long>(stack_env, 1), (long)stack_need);
+#endif
     c->bvh_deepest_leaf = deepest_leaf;
     // what one scan of the world's list entries tests (a medium's boundary list is scanned at least once per scan
     // of the list that holds the medium): the per-segment list term of the algorithmic work
@@ -643,6 +655,7 @@ int mirt_frame_begin(mirt_ctx* c, uint32_t width, uint32_t height, float* accum_
     HIP_TRY(c, hipMemsetAsync(c->accum, 0, pixels * sizeof(float4), c->stream));
     HIP_TRY(c, hipMemsetAsync(c->seg_counter, 0, kWorkCounterOffset, c->stream));  // statistics and the fault word
     c->stats = mirt_stats{};
+    c->reduce_timed = false;
     return MIRT_OK;
 }
 
@@ -770,7 +783,10 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
     // the persistent kernel packs a pixel position into 16 + 16 bits: larger frames go to the one-pixel-per-lane kernel
     if (p->width > 0xffffu || p->height > 0xffffu) a.loop = LOOP_FUSED;
     a.debug_drop_pixel = 0xffffffffu;
-    if (const char* e = std::getenv("MIRT_DEBUG_DROP_PIXEL")) a.debug_drop_pixel = (uint32_t)std::atol(e);  // tests of the stale-slot report
+#ifdef MIRT_DEBUG_HOOKS
+    static const long drop_env = [] { const char* e = std::getenv("MIRT_DEBUG_DROP_PIXEL"); return e ? std::atol(e) : -1l; }();
+    if (drop_env >= 0) a.debug_drop_pixel = (uint32_t)drop_env;  // tests of the stale-slot report
+#endif
     {
         // How the persistent kernel shares a wave between its walks (kernels.h). Measured at 1080p with
         // (lanes walking, lanes descending) out of 64: `random` 1 740 Msamples/s with whole walks, 2 300 with
@@ -787,8 +803,8 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
     }
     // Long renders are cut into launches of at most kChunk samples per pixel: lanes of a wave
     // then finish within a few percent of each other and no launch runs for seconds.
-    uint32_t kChunk = 1024;  // measured on Cornell 1080p: 64 -> 9.5, 256 -> 10.6, 1024 -> 11.2 Gsamples/s (fewer launch tails)
-    if (const char* env = std::getenv("MIRT_CHUNK_SPP")) { int v = std::atoi(env); if (v > 0) kChunk = (uint32_t)v; }
+    // measured on Cornell 1080p: 64 -> 9.5, 256 -> 10.6, 1024 -> 11.2 Gsamples/s (fewer launch tails)
+    static const uint32_t kChunk = [] { const char* e = std::getenv("MIRT_CHUNK_SPP"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 1024u; }();
     static const uint32_t split = [] {
         const char* e = std::getenv("MIRT_SPLIT");
         const long v = e ? std::atol(e) : 0;
@@ -825,9 +841,14 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
             }
         }
         a.partial = sc.may_allocate ? c->partial : sc.partial;
-        if (++c->stamp == 0) c->stamp = 1;
-        // (a stamp is a float's bit pattern in a slot nobody reads as a float; it only has to differ from launch to launch)
-        a.stamp = c->stamp;
+        // (a stamp is a float's bit pattern in a slot nobody reads as a float; it only has to differ from launch to
+        // launch among the launches that fill the same buffer: the context's own, or the device's static scratch)
+        if (sc.may_allocate) {
+            if (++c->stamp == 0) c->stamp = 1;
+            a.stamp = c->stamp;
+        } else {
+            a.stamp = static_scratch_next_stamp();
+        }
         if (wavefront) {
             const int rc = render_wavefront_launch(c, a, &launches);
             if (rc) return rc;
@@ -859,6 +880,9 @@ int mirt_render_static(mirt_ctx* c, const mirt_render_params* p) {
                                              " pixels, two chunk images in the static scratch) or 65535 in one dimension");
     if (!c->static_scratch) return fail(c, MIRT_ERR_STATE, "mirt_render_static: no static scratch on this device");
     char* base = static_cast<char*>(c->static_scratch);
+    mirt_render_params q = *p;
+    q.kernel = MIRT_KERNEL_QUEUE;  // AUTO would hand a lone-primitive scene to the one-pixel-per-lane kernel
+    p = &q;
     return render_impl(c, p, "mirt_render_static",
                        RenderScratch{reinterpret_cast<uint32_t*>(base), reinterpret_cast<float4*>(base + kStaticPartialOffset), kStaticPartialBytes, false});
 }
@@ -1028,6 +1052,10 @@ int mirt_get_stats(mirt_ctx* c, mirt_stats* out) {
     if (c->stats.kernel_launches) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->stats.kernel_ms = ms;
+    }
+    if (c->reduce_timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_r0, c->ev_r1) == hipSuccess) c->stats.reduce_ms = ms;
     }
     *out = c->stats;
     return MIRT_OK;

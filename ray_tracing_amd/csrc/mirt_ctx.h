@@ -19,7 +19,9 @@ constexpr size_t kFaultOffset = 64, kWorkCounterOffset = 128;
 struct mirt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;    // around the launches of the last mirt_render
+    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;  // around the last reduce of the accumulation buffer (comm.cpp)
+    bool reduce_timed = false;                  // ... which was recorded since mirt_frame_begin
     std::string err;
     std::vector<void*> scene_allocs;
     mirt::DevScene scene{};

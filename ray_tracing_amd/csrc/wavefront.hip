@@ -28,6 +28,7 @@
 // host only fetches the live counts after each batch of rounds.
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include "wavefront.h"
 #include "dev_core.h"
 
@@ -132,7 +133,9 @@ __device__ __forceinline__ void begin_item(const RenderArgs& r, uint32_t x, uint
 // accumulation buffer, otherwise to the item's own slot of the chunk sums, stamped (see RenderArgs::stamp).
 __device__ __forceinline__ void store_item(const RenderArgs& r, const PathRegs& p) {
     const uint32_t chunk = (p.sample_end - 1u - r.spp_begin) / r.chunk_spp;
+#ifdef MIRT_DEBUG_HOOKS
     if (p.pixel == r.debug_drop_pixel && chunk == 0u) return;
+#endif
     if (r.n_chunks == 1u) {
         float4 v = r.accum[p.pixel];
         v.x += p.acc.x; v.y += p.acc.y; v.z += p.acc.z; v.w += (float)r.spp_count;
@@ -459,19 +462,25 @@ hipError_t wf_launch_finish(const WfArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Workgroups the device keeps resident of the walk kernel with `lds_bytes` of stack (asked once per variant and size).
+// Workgroups the device keeps resident of the walk kernel with `lds_bytes` of stack (asked once per variant, device
+// and size).
 template <uint32_t F>
 static hipError_t walk_grid(size_t lds_bytes, uint32_t* out) {
+    static std::mutex mu;
     static uint32_t cached = 0;
     static size_t cached_for = 0;
-    if (!cached || cached_for != lds_bytes) {
-        int device = 0, cus = 0, per_cu = 0;
-        hipError_t e = hipGetDevice(&device);
-        if (e != hipSuccess) return e;
+    static int cached_device = -1;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!cached || cached_for != lds_bytes || cached_device != device) {
+        int cus = 0, per_cu = 0;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, wf_walk_kernel<F>, kWfBlock, lds_bytes)) != hipSuccess) return e;
         cached = (uint32_t)(cus * per_cu > 0 ? cus * per_cu : 1);
         cached_for = lds_bytes;
+        cached_device = device;
         if (std::getenv("MIRT_WF_DEBUG")) fprintf(stderr, "wf_walk_kernel: %d CUs x %d workgroups resident with %zu bytes of LDS stack\n", cus, per_cu, lds_bytes);
     }
     *out = cached;
@@ -490,7 +499,11 @@ static hipError_t launch_round(const WfArgs& a, hipStream_t stream) {
             const size_t lds_bytes = (size_t)(a.r.scene.stack_limit + kBvhStackSlack) * kWfBlock * sizeof(uint32_t);
             hipError_t e = walk_grid<F>(lds_bytes, &resident);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(wf_walk_kernel<F>, dim3(std::min(std::min(resident, pool.x), WF_MAX_WALK_GROUPS)), block, lds_bytes, stream, a);
+            // At least WF_LANES workgroups, resident at once or not: a workgroup starts at queue lane blockIdx mod
+            // WF_LANES and draws from a few lanes from there on, so fewer workgroups than lanes (a small device or
+            // partition) would leave some lanes' records unwalked. (pool.x >= WF_LANES.)
+            hipLaunchKernelGGL(wf_walk_kernel<F>, dim3(std::min(std::min(std::max(resident, (uint32_t)WF_LANES), pool.x), WF_MAX_WALK_GROUPS)), block, lds_bytes,
+                               stream, a);
         }
     }
     if (is_pinhole(a)) hipLaunchKernelGGL((wf_shade_kernel<F, true>), pool, block, 0, stream, a);

@@ -41,6 +41,17 @@ def earth(rt):
     return e
 
 
+def observe(test, **values):
+    """Append what a tolerance test saw (close-pixel share, worst difference, ...) to gpurun_out/observed_parity.jsonl:
+    the thresholds in the tests are these observations minus a stated margin, and the file shows how much is left."""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "observed_parity.jsonl"), "a") as f:
+            f.write(json.dumps({"test": test, **{k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in values.items()}}) + "\n")
+    except OSError:
+        pass
+
+
 def kat_rays(kat):
     o = kat["camera"]["origin"]
     return np.array([o + r["dir"] + [0.5] for r in kat["rays"]], dtype=np.float32)

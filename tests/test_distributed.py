@@ -1,4 +1,4 @@
-"""World-size-2 check of the multi-GPU path on CPU (gloo): sample-range split + one reduce of the float4
+"""World-size 2, 3 and 8 checks of the multi-GPU path on CPU (gloo): sample-range split + one reduce of the float4
 accumulation buffers. The per-rank render is done by the oracle here (no GPU in this process); on the GPU
 box bench.py runs the same split and reduce with the HIP renderer and the nccl (RCCL) backend."""
 import os
@@ -30,7 +30,9 @@ def _worker(rank, world, port, mode, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     begin, count = sample_range(SPP, world, rank) if mode == "strong" else weak_range(SPP, rank)
     r = oracle.OracleRenderer("cornell", W, H)
-    sums, _ = r.render_sums(count, DEPTH, seed=4, spp_begin=begin, threads=2)
+    sums = np.zeros((H, W, 3), dtype=np.float32)
+    if count:
+        sums, _ = r.render_sums(count, DEPTH, seed=4, spp_begin=begin, threads=1, total_spp=SPP if mode == "strong" else world * SPP)
     acc = np.concatenate([sums, np.full((H, W, 1), count, dtype=np.float32)], axis=2)
     t = torch.from_numpy(acc.reshape(-1).copy())
     reduce_accum(t, dst=0)
@@ -54,14 +56,16 @@ def test_sample_range_partition():
         sample_range(4, 2, 2)
 
 
-@pytest.mark.parametrize("mode", ["strong", "weak"])
-def test_two_ranks_reduce_equals_single_render(tmp_path, mode):
+@pytest.mark.parametrize("mode,world", [("strong", 2), ("weak", 2), ("strong", 3), ("weak", 3), ("strong", 8)])
+def test_ranks_reduce_equals_single_render(tmp_path, mode, world):
+    """World sizes 2, 3 (uneven split: 7 samples over 3 ranks) and 8 (more ranks than samples: one rank renders
+    nothing and still takes part in the reduce)."""
     sys.path.insert(0, ROOT)
     import oracle
     out = str(tmp_path / "acc.npy")
-    mp.spawn(_worker, args=(2, _free_port(), mode, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, out), nprocs=world, join=True)
     got = np.load(out)
-    total = SPP if mode == "strong" else 2 * SPP
+    total = SPP if mode == "strong" else world * SPP
     want, _ = oracle.OracleRenderer("cornell", W, H).render_sums(total, DEPTH, seed=4)
     assert (got[..., 3] == total).all()
     np.testing.assert_allclose(got[..., :3], want, rtol=1e-5, atol=1e-6)

@@ -7,12 +7,21 @@ import math
 import numpy as np
 import pytest
 
-from conftest import kat_rays
+from conftest import kat_rays, observe
 
 pytestmark = pytest.mark.gpu
 
 SCENES = ["cornell", "smoke", "random", "final", "2sp", "2psp", "earth", "simplelight"]
 W, H = 64, 36
+# Tolerance tables. A sample or pixel falls outside the tolerance only when a last-bit difference between the device's
+# arithmetic (hardware reciprocal / square root / sine, fused multiply-adds in shading) and the oracle's diverts a
+# path: another side of an edge, a rejection-sampling trial accepted on one side only. Each bound is what was observed
+# on the MI355X (gpurun_out/observed_parity.jsonl, written by every run) with a margin of about half the observed
+# shortfall again, so a change that diverts noticeably more paths than today fails. Placeholders until observed: the
+# old global bounds.
+SAMPLE_DIVERTED_MAX = {name: 0.01 for name in SCENES}
+IMAGE_CLOSE_MIN = {name: 0.97 for name in SCENES}
+RAGGED_CLOSE_MIN = {(37, 19): 0.95, (8, 8): 0.95, (33, 9): 0.95, (2, 2): 0.95}
 
 
 def sanitise(c):
@@ -140,7 +149,8 @@ def test_single_samples_match_oracle(rt, oracle, earth, name):
         oc, gc = sanitise(oc), sanitise(gc)
         bad = ~np.isclose(oc, gc, rtol=2e-3, atol=1e-4)
         bad_total += bad.any(axis=1).sum()
-    assert bad_total <= 0.01 * 2 * len(rays), bad_total
+    observe("single_samples", scene=name, diverted_share=bad_total / (2 * len(rays)))
+    assert bad_total <= SAMPLE_DIVERTED_MAX[name] * 2 * len(rays), bad_total
 
 
 @pytest.mark.parametrize("name,spp,depth", [("cornell", 64, 50), ("smoke", 32, 50), ("random", 32, 50), ("final", 16, 50),
@@ -166,7 +176,9 @@ def test_accumulated_image_matches_oracle(rt, oracle, earth, name, spp, depth):
     else:
         assert abs(st["segments"] - int(cnt[0])) <= 0.002 * int(cnt[0]) + 2  # same paths -> same segment count
     close = np.isclose(got, want, rtol=5e-3, atol=5e-3 * spp * 0.05)
-    assert close.all(axis=2).mean() > 0.97
+    observe("accumulated_image", scene=name, close_share=close.all(axis=2).mean(), worst=np.abs(got - want).max(),
+            mean_rel=abs(got.mean() - want.mean()) / want.mean())
+    assert close.all(axis=2).mean() >= IMAGE_CLOSE_MIN[name], close.all(axis=2).mean()
     # A pixel that is not close holds a path that a last-bit difference diverted (another side of an edge, a free
     # path that ends a hair earlier): its SUM then differs by what one sample can carry, not by an arbitrary amount.
     # One sample carries at most the brightest source of the scene times a weight of order one: measured worst cases
@@ -536,7 +548,9 @@ def test_ragged_frame_sizes(rt, oracle, earth, w, h):
         ctx.render(8, 50, seed=2, kernel=kernel)
         acc = ctx.read_accum()
         assert acc.shape == (h, w, 4) and (acc[..., 3] == 8).all()
-        assert np.isclose(acc[..., :3], want, rtol=5e-3, atol=2e-3).all(axis=2).mean() > 0.95
+        share = np.isclose(acc[..., :3], want, rtol=5e-3, atol=2e-3).all(axis=2).mean()
+        observe("ragged_frame", size=[w, h], kernel=int(kernel), close_share=share)
+        assert share >= RAGGED_CLOSE_MIN[(w, h)], share
     frame = ctx.resolve_rgba8()
     assert frame.shape == (h, w, 4) and (frame[..., 3] == 255).all()
 

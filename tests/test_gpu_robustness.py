@@ -14,8 +14,21 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+DEBUG_LIB = os.path.join(ROOT, "ray_tracing_amd", "libmirt_debug.so")   # the build with the test hooks (MIRT_DEBUG_*)
+
+
 def _run_child(code, **env):
     e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+    if any(k.startswith("MIRT_DEBUG_") for k in env):
+        assert os.path.exists(DEBUG_LIB), "build ray_tracing_amd/libmirt_debug.so (make -C ray_tracing_amd/csrc)"
+        e["MIRT_LIB"] = DEBUG_LIB
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=e, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
     return r.stdout
@@ -254,6 +267,6 @@ def test_rccl_reduce_one_process_per_gpu(rt):
             f"if rank == 0: np.save(r'{out}', ctx.read_accum())\n"
             "dist.barrier(); dist.destroy_process_group()\n")
         r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                            "--master-port", "29731", "--no-python", sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=110)
+                            "--master-port", str(_free_port()), "--no-python", sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=110)
         assert r.returncode == 0, r.stdout + r.stderr
         np.testing.assert_allclose(np.load(out), full, rtol=1e-5, atol=1e-5)

@@ -33,8 +33,8 @@ def test_struct_sizes_match_header(rt):
     assert ctypes.sizeof(rt.mirt_material) == 24
     assert ctypes.sizeof(rt.mirt_texture) == 40
     assert ctypes.sizeof(rt.mirt_perlin) == 256 * 12 + 768
-    assert ctypes.sizeof(rt.mirt_stats) == 3 * 8 + 2 * 4 + 8 + 3 * 8 + 6 * 4 + 8
-    assert rt.mirt_stats.device_faults.offset == 76 and rt.mirt_stats.bvh_box_tests.offset == 88
+    assert ctypes.sizeof(rt.mirt_stats) == 3 * 8 + 2 * 4 + 8 + 3 * 8 + 6 * 4 + 8 + 8
+    assert rt.mirt_stats.device_faults.offset == 76 and rt.mirt_stats.bvh_box_tests.offset == 88 and rt.mirt_stats.reduce_ms.offset == 96
     assert rt.mirt_stats.device_faults.offset == 76
 
 

@@ -1,6 +1,6 @@
 """GPU test of mirt_render_static, the render entry point that allocates nothing: through the C ABI, against
 mirt_render on the same inputs, on two calls in a row — the second with a smaller frame, so it finds the first
-call's sums and counters in the static scratch. Where the frame fits sixteen chunk images both entry points add
+call's sums and counters in the static scratch. Where the frame fits sixteen chunk images (256 Ki pixels) both entry points add
 the same floats in the same order: the accumulation buffers are equal bit for bit. A larger frame gets fewer,
 longer chunks from the static scratch, i.e. another grouping of the same additions: rtol 2e-6, the bar the two
 render loops are held to among themselves."""
@@ -32,7 +32,7 @@ def test_static_scratch_render_equals_allocating_render(rt, earth, name):
     assert (got[..., 3] == 5).all() and (got == want).all()
     got, want = _pair(rt, ctx, 64, 36, 1, 50, 4)                    # one sample: one chunk, straight into the sums
     assert (got == want).all()
-    # 1920x1080: eight chunk images fit, mirt_render uses sixteen
+    # 1920x1080: two chunk images fit, mirt_render uses sixteen
     got, want = _pair(rt, ctx, 1920, 1080, 32 if name == "cornell" else 16, 50, 5)
     assert (got[..., 3] == want[..., 3]).all()
     np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-6)
@@ -53,7 +53,7 @@ def test_static_scratch_render_rejects_what_does_not_fit(rt):
         ctx.render_static(2, 5, kernel=rt.KERNEL_FUSED)
     ctx.render_static(2, 5)
     assert (ctx.read_accum()[..., 3] == 2).all()
-    # 3840x2160 fits with two chunk images
+    # 3840x2160: not even two chunk images fit: whole pixels as work items, straight into the sums
     ctx.frame_begin(3840, 2160)
     ctx.render_static(2, 5, seed=1)
     a = ctx.read_accum()
