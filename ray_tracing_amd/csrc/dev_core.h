@@ -64,6 +64,19 @@ MIRT_DEV T load_const(const T* p) {
     for (int i = 0; i < kWords; ++i) u.words[i] = q[i];
     return u.value;
 }
+// A launch argument read again from the kernel-argument segment where it is used (p points into that segment: a
+// scalar load). The empty asm makes the pointer a new value to the compiler at every use, so it can neither hoist
+// the load out of the render loop nor keep the value in scalar registers across it: arguments needed once in a
+// few hundred iterations (the item bookkeeping) or only by some branch (the camera) would otherwise take scalar
+// registers for the whole loop, and what no longer fits is spilled to vector-register lanes — v_readlane /
+// v_writelane, which compete with the arithmetic for issue slots where a scalar load does not.
+template <class T>
+MIRT_DEV T reload(const __attribute__((address_space(4))) T* p) {
+#ifdef __HIP_DEVICE_COMPILE__
+    asm volatile("" : "+s"(p));
+#endif
+    return load_const((const T*)p);
+}
 
 // Two floats in a register pair: + - * and fma on them are single packed instructions (v_pk_add_f32,
 // v_pk_mul_f32, v_pk_fma_f32), each half rounded exactly as the scalar operation would be.
@@ -136,6 +149,15 @@ MIRT_DEV LRay make_lray(const Ray& r) {
 // ---------------------------------------------------------------------------------------------
 enum : uint32_t { STREAM_CAMERA = 0, STREAM_SCATTER = 1, STREAM_MEDIUM = 2 };
 
+// a ^ b ^ c in one instruction (v_bitop3_b32 with the truth table of the three-input xor)
+MIRT_DEV uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+// A round is two 32 x 32 -> 64 bit products, two key additions and two three-input xors: six vector instructions.
 MIRT_DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t& o0,
                             uint32_t& o1, uint32_t& o2, uint32_t& o3) {
     const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
@@ -143,8 +165,8 @@ MIRT_DEV void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, 
     for (int r = 0; r < 10; ++r) {
         uint64_t p0 = (uint64_t)M0 * c0;
         uint64_t p1 = (uint64_t)M1 * c2;
-        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         c1 = (uint32_t)p1;
         c3 = (uint32_t)p0;
         c0 = n0;

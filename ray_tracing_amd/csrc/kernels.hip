@@ -310,8 +310,34 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         tb = Tables{a.scene.prims, a.scene.shade, a.scene.instances, a.scene.light_prims};
     }
 
-    const uint32_t tiles_x = (a.width + 7u) / 8u, tiles_y = (a.height + 7u) / 8u;
-    const uint32_t n_tiles = tiles_x * tiles_y;
+    // The launch arguments where they lie in memory. The variant that carries every feature (`final`: media, noise and
+    // image textures, two hierarchies) reads them from there at the point of use — the item bookkeeping when an item
+    // ends, the camera when a path starts, the scene's tables once per phase of an iteration — instead of holding them
+    // in scalar registers for the whole loop: it has far more live scalars than registers, and what does not fit is
+    // spilled to vector-register lanes, v_readlane / v_writelane, which compete with the arithmetic for issue slots
+    // (342 of them in its code; 60 with the reloads; `final` +5 %). The smaller variants fit or nearly fit and lose
+    // 1-2 % to the scalar loads' latency (measured per group of arguments, profiles/r3): they keep their arguments in
+    // registers.
+    constexpr bool kReloadArgs = (F & (F_TEX_NOISE | F_TEX_IMAGE)) != 0;
+    const __attribute__((address_space(4))) RenderArgs* const ka = (const __attribute__((address_space(4))) RenderArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    auto scene_now = [&]() -> DevScene {
+        if constexpr (kReloadArgs) return reload(&ka->scene);
+        else return a.scene;
+    };
+    auto tables_now = [&]() -> Tables {
+        if constexpr (kReloadArgs && !LDS_TABLES) {
+            const DevScene sc = reload(&ka->scene);
+            return Tables{sc.prims, sc.shade, sc.instances, sc.light_prims};
+        } else {
+            return tb;
+        }
+    };
+    auto cam_now = [&]() -> DevCamera {
+        if constexpr (kReloadArgs) return reload(&ka->cam);
+        else return a.cam;
+    };
+#define MIRT_ITEM_ARG(field) (kReloadArgs ? reload(&ka->field) : a.field)
+
     const bool jitter = a.jitter != 0;
     const uint32_t max_depth = a.max_depth;
     ItemQueue q{64u, 0u, 0u};
@@ -340,16 +366,15 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
 
     // Gives the lanes with `need` their next pixel: position, first sample, empty sums. Indices of the edge
     // tiles that lie outside the frame are skipped. A lane that gets none is done (alive = false).
-    // (the closures below capture copies of the few launch arguments they need: a reference to the
-    // argument block would move it to memory and turn every scene read into a per-lane load)
-    uint32_t* const work_counter = a.work_counter;
-    float4* const accum = a.accum;
-    const uint32_t width = a.width, height = a.height, spp_begin = a.spp_begin, spp_last = a.spp_begin + a.spp_count;
-    const uint32_t chunk_spp = a.chunk_spp, n_chunks = a.n_chunks, n_pixels = a.width * a.height;
-    const float spp_count = (float)a.spp_count;
-    float4* const partial = a.partial;
-    auto next_pixel = [&q, &alive, &xy, &pixel, &sample, &sample_end, &acc, work_counter, n_tiles, tiles_x, n_chunks, width, height,
-                       spp_begin, spp_last, chunk_spp](bool need) {
+    // (the closures below read the launch arguments they need when they run — an item ends once in a few hundred
+    // iterations)
+    auto next_pixel = [&q, &alive, &xy, &pixel, &sample, &sample_end, &acc, &a, ka](bool need) {
+        if (__ballot(need) == 0) return;
+        (void)ka;
+        uint32_t* const work_counter = MIRT_ITEM_ARG(work_counter);
+        const uint32_t width = MIRT_ITEM_ARG(width), height = MIRT_ITEM_ARG(height), spp_begin = MIRT_ITEM_ARG(spp_begin);
+        const uint32_t spp_last = spp_begin + MIRT_ITEM_ARG(spp_count), chunk_spp = MIRT_ITEM_ARG(chunk_spp), n_chunks = MIRT_ITEM_ARG(n_chunks);
+        const uint32_t tiles_x = (width + 7u) / 8u, n_tiles = tiles_x * ((height + 7u) / 8u);
         for (;;) {
             if (__ballot(need) == 0) break;
             uint32_t chunk = 0, x = 0, y = 0;
@@ -377,7 +402,13 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
 #else
     constexpr uint32_t drop_pixel = 0xffffffffu;  // the hook exists only in the test build of the library
 #endif
-    auto flush_pixel = [&pixel, &sample_end, &acc, accum, partial, spp_count, n_chunks, n_pixels, spp_begin, chunk_spp, stamp, drop_pixel]() {
+    auto flush_pixel = [&pixel, &sample_end, &acc, &a, ka, stamp, drop_pixel]() {
+        const uint32_t spp_begin = MIRT_ITEM_ARG(spp_begin), chunk_spp = MIRT_ITEM_ARG(chunk_spp), n_chunks = MIRT_ITEM_ARG(n_chunks);
+        const uint32_t n_pixels = MIRT_ITEM_ARG(width) * MIRT_ITEM_ARG(height);
+        const float spp_count = (float)MIRT_ITEM_ARG(spp_count);
+        float4* const accum = MIRT_ITEM_ARG(accum);
+        float4* const partial = MIRT_ITEM_ARG(partial);
+        (void)ka;
         const uint32_t chunk = (sample_end - 1u - spp_begin) / chunk_spp;
 #ifdef MIRT_DEBUG_HOOKS
         if (pixel == drop_pixel && chunk == 0u) return;
@@ -396,7 +427,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     if (alive) {
         Rng g;
         g.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
-        ray = camera_ray<PINHOLE>(a.cam, xy & 0xffffu, xy >> 16, a.width, a.height, jitter, g);
+        ray = camera_ray<PINHOLE>(cam_now(), xy & 0xffffu, xy >> 16, a.width, a.height, jitter, g);
     }
     while (__ballot(alive) != 0) {
         ++rounds;
@@ -412,10 +443,10 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 DrawKey key{pixel, sample, bounce, a.seed};
                 wk.closest = MIRT_INF;
                 wk.best = -1;
-                world_lists<FT>(a.scene, ray, key, wk.closest, wk.best);
+                world_lists<FT>(scene_now(), ray, key, wk.closest, wk.best);
                 wk.next = 0;
                 wk.ref = kWalkIdle;
-                walk_n = walk_count(a.scene, ray);
+                walk_n = walk_count(scene_now(), ray);
             }
             segments += (uint32_t)__popcll(__ballot(alive && !walking && !closed));
             uint32_t wsteps = 0;
@@ -423,7 +454,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
             // the lane thresholds are stated for a full wave: scale them to the lanes this wave still has
             const uint32_t live = (uint32_t)__popcll(__ballot(alive));
             if (alive && !closed)
-                walking = !walk_some<FT>(a.scene, ray, 0.001f, wk, walk_n, walk_budget, (walk_min_lanes * live) >> 6,
+                walking = !walk_some<FT>(scene_now(), ray, 0.001f, wk, walk_n, walk_budget, (walk_min_lanes * live) >> 6,
                                          (walk_node_lanes * live) >> 6, stack, kBlock, wsteps, wave_cost);
             MIRT_STATS(tc2 = clock64());
             MIRT_STATS(walk_histogram(alive, wsteps));
@@ -432,7 +463,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
             prim = wk.best;
         } else if (alive && !closed) {
             DrawKey key{pixel, sample, bounce, a.seed};
-            world_hit<FT>(a.scene, ray, key, stack, kBlock, t, prim);
+            world_hit<FT>(scene_now(), ray, key, stack, kBlock, t, prim);
         }
         if constexpr ((FT & F_BVH) == 0) segments += (uint32_t)__popcll(__ballot(alive && !closed));
         if constexpr ((FT & F_BVH) == 0) { MIRT_STATS(tc1 = tc2 = clock64()); }
@@ -446,13 +477,14 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         } else if (ready) {
             V3 e = v3(0.f, 0.f, 0.f);
             if (prim < 0) {
-                e = cmul(thr, v3(a.scene.background));  // renderer.rs:233-235
+                e = cmul(thr, v3(scene_now().background));  // renderer.rs:233-235
                 ended = true;
             } else {
-                m = tb.shade[prim];
-                h = finalize_hit<F>(tb, ray, t, prim, m.tex_kind == TK_IMAGE);
+                const Tables tbn = tables_now();
+                m = tbn.shade[prim];
+                h = finalize_hit<F>(tbn, ray, t, prim, m.tex_kind == TK_IMAGE);
                 if ((F & F_MAT_LIGHT) && m.mat_kind == MK_DIFFUSE_LIGHT) {
-                    e = cmul(thr, emitted_radiance<F>(a.scene, m, h));
+                    e = cmul(thr, emitted_radiance<F>(scene_now(), m, h));
                     ended = true;
                 }
             }
@@ -479,7 +511,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         g.init_with_block0(pixel, sample, r_bounce, r_stream, a.seed, w0, w1, w2, w3);
 
         if (ready && alive && !ended) {
-            const bool cont = scatter<F>(a.scene, tb, m, h, g, ray, thr);
+            const bool cont = scatter<F>(scene_now(), tables_now(), m, h, g, ray, thr);
             ++bounce;
             // absorbed, or renderer.rs:198-200: the next level returns 0. The sample is complete; its lane sits
             // out the trace of the next iteration and gets there what every path that ends gets: the item
@@ -490,7 +522,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 closed = true;
             }
         } else if (ready && alive) {
-            ray = camera_ray<PINHOLE>(a.cam, xy & 0xffffu, xy >> 16, a.width, a.height, jitter, g);
+            ray = camera_ray<PINHOLE>(cam_now(), xy & 0xffffu, xy >> 16, a.width, a.height, jitter, g);
             thr = v3(1.f, 1.f, 1.f);
             bounce = 0;
         }

@@ -60,3 +60,47 @@ def test_static_scratch_render_rejects_what_does_not_fit(rt):
     ctx.frame_begin(3840, 2160)
     ctx.render(2, 5, seed=1)
     assert (a == ctx.read_accum()).all()
+
+
+def test_static_scratch_render_allocates_nothing(rt):
+    """What the entry point exists for: no device memory is allocated or freed by the call. A fresh context that never
+    went through mirt_render, a caller-owned accumulation buffer (so mirt_frame_begin allocates nothing either), one
+    warm-up call (the first launch of a kernel makes the runtime load it), then free device memory (hipMemGetInfo)
+    before and after calls with more samples and with another frame size: unchanged to the byte."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    ctx = rt.Context(0)
+    ctx.scene_upload(rt.select_scene("cornell"))
+    ctx.camera_set(rt.Camera.select_camera(16 / 9, "cornell"))
+    buf = C.c_void_p()
+    assert hip.hipMalloc(C.byref(buf), 1920 * 1080 * 16) == 0
+    try:
+        ctx.frame_begin(320, 180, buf)
+        ctx.render_static(4, 10, seed=1)                             # warm-up
+        ctx.synchronize()
+        before = free_bytes()
+        ctx.frame_begin(320, 180, buf)
+        ctx.render_static(40, 50, seed=2)                            # more samples: sixteen chunks
+        ctx.frame_begin(1920, 1080, buf)
+        ctx.render_static(8, 50, seed=3)                             # larger frame: two chunk images
+        ctx.frame_begin(64, 36, buf)
+        ctx.render_static(3, 50, seed=4)
+        ctx.synchronize()
+        assert free_bytes() == before
+        assert ctx.stats()["device_faults"] == 0
+        ctx.frame_begin(64, 36, buf)
+        ctx.render_static(3, 50, seed=4)
+        a = ctx.read_accum()
+        assert (a[..., 3] == 3).all() and np.isfinite(a).all()
+    finally:
+        ctx.synchronize()
+        del ctx
+        hip.hipFree(buf)
