@@ -148,6 +148,10 @@ enum { MIRT_KERNEL_AUTO = 0, MIRT_KERNEL_FUSED = 1, MIRT_KERNEL_WAVEFRONT = 2, M
  * hierarchy walks cost (mirt_stats.bvh_*). Tallying slows the launch by a few percent: for measurement passes, not
  * for timed ones. */
 #define MIRT_KERNEL_COUNT_WALKS 0x100u
+/* OR-ed into MIRT_KERNEL_WAVEFRONT: after the intersection stages of a round the paths are filed into one queue per
+ * class of what they do next — the ScatterType of material.rs:19-23 (Diffuse, Specular, ISO) and the paths that end
+ * (miss, emitter) — and the shading stage runs once per class. Same samples, same sums. */
+#define MIRT_KERNEL_WF_CLASSES 0x200u
 
 typedef struct mirt_render_params {
     uint32_t width, height;

@@ -693,6 +693,7 @@ int wf_ensure(mirt_ctx* c, uint32_t slots) {
         if ((rc = wf_alloc(c, &st.q_d[k], entries))) return rc;
         if ((rc = wf_alloc(c, &st.q_h[k], entries))) return rc;
     }
+    if ((rc = wf_alloc(c, &st.cls, (size_t)WC_COUNT * entries))) return rc;
     if ((rc = wf_alloc(c, &st.ctl, (size_t)WF_CTL_WORDS))) return rc;
     if ((rc = wf_alloc(c, &st.cost, (size_t)WF_MAX_WALK_GROUPS * 4))) return rc;
     HIP_TRY(c, hipMemset(st.cost, 0, (size_t)WF_MAX_WALK_GROUPS * 4 * sizeof(unsigned long long)));
@@ -706,7 +707,7 @@ int wf_ensure(mirt_ctx* c, uint32_t slots) {
 // set: rounds are enqueued in batches without reading anything back; after a batch the live count of the pool comes
 // to the host, and the render is over when it is zero. Rounds enqueued past the end find empty queues and cost a
 // few microseconds each; the batches grow with the render so that neither they nor the read-backs matter.
-int render_wavefront_launch(mirt_ctx* c, const RenderArgs& a, uint32_t* launches) {
+int render_wavefront_launch(mirt_ctx* c, const RenderArgs& a, bool by_class, uint32_t* launches) {
     static const uint32_t pool = [] { const char* e = std::getenv("MIRT_WF_POOL"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : (1u << 22); }();
     static const uint32_t refill = [] { const char* e = std::getenv("MIRT_WF_REFILL"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)std::min(v, 64l) : 16u; }();
     static const uint32_t fetch_run = [] { const char* e = std::getenv("MIRT_WF_RUN"); const long v = e ? std::atol(e) : 0; return v > 0 ? (uint32_t)v : 128u; }();
@@ -723,6 +724,7 @@ int render_wavefront_launch(mirt_ctx* c, const RenderArgs& a, uint32_t* launches
     w.lane_capacity = wf_lane_capacity(capacity);
     w.refill_lanes = refill;
     w.fetch_run = fetch_run;
+    w.by_class = by_class ? 1u : 0u;
     HIP_TRY(c, wf_launch_init(w, c->stream));
     ++*launches;
     uint32_t round = 0, batch = 8;
@@ -765,7 +767,7 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
     if (!c->accum || p->width != c->width || p->height != c->height)
         return fail(c, MIRT_ERR_STATE, w + ": width/height differ from mirt_frame_begin");
     if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, w + ": sample range overflows 32 bits");
-    if ((p->kernel & 0xffu) > MIRT_KERNEL_QUEUE || (p->kernel & ~(0xffu | MIRT_KERNEL_COUNT_WALKS))) return fail(c, MIRT_ERR_INVALID, w + ": unknown kernel selector");
+    if ((p->kernel & 0xffu) > MIRT_KERNEL_QUEUE || (p->kernel & ~(0xffu | MIRT_KERNEL_COUNT_WALKS | MIRT_KERNEL_WF_CLASSES))) return fail(c, MIRT_ERR_INVALID, w + ": unknown kernel selector");
     const uint32_t selector = p->kernel & 0xffu;
     HIP_TRY(c, hipSetDevice(c->device));
     RenderArgs a{};
@@ -850,7 +852,7 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
             a.stamp = static_scratch_next_stamp();
         }
         if (wavefront) {
-            const int rc = render_wavefront_launch(c, a, &launches);
+            const int rc = render_wavefront_launch(c, a, (p->kernel & MIRT_KERNEL_WF_CLASSES) != 0, &launches);
             if (rc) return rc;
             continue;
         }

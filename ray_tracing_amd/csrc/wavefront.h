@@ -21,6 +21,11 @@ struct WfState {
     float4* q_d[2];  // direction.xyz, t of the closest hit so far
     uint2* q_h[2];   // bits of the hit primitive (int, -1 = none), slot
     uint32_t* ctl;   // control words, WF_CTL_*
+    // Class queues (WfArgs::by_class): after the intersection stages every record of the round's queue is filed under
+    // what its path does next — ScatterType of material.rs:19-23 plus the paths that end: WC_* below — as an index
+    // into the round's queue; cls[(class * WF_LANES + lane) * lane_capacity + i], counts in the control words. The
+    // shading stage then runs once per class, each launch over lanes that all take the same branch.
+    uint32_t* cls;
     unsigned long long* cost;  // per workgroup of the walk kernel: node steps, leaf spheres, leaf rects, child boxes (summed at the end)
 };
 constexpr uint32_t WF_MAX_WALK_GROUPS = 4096;
@@ -37,9 +42,14 @@ enum : uint32_t {
     WF_CTL_N1 = 1,       // entries in lane k of q[1]
     WF_CTL_CURSOR = 2,   // fetch position of the walk kernel in lane k of this round's queue
     WF_CTL_ITEM = 3,     // work items handed out by counter k
+    WF_CTL_CLASS = 4,    // four words: records of lane k filed under class 0 .. 3 this round
     WF_CTL_WORDS = (WF_LANES + 1) * WF_CTL_STRIDE,
     WF_CTL_ITEMS_SPENT = WF_LANES * WF_CTL_STRIDE,  // two words: which item counters were spent when the round began
 };
+
+// What a path does after its hit is known: it ends (miss, or an emitter: material.rs:167-175 never scatters), or its
+// material scatters as ScatterType::Diffuse (Lambertian), ::Specular (Metal, Dielectric) or ::ISO (Isotropic).
+enum : uint32_t { WC_ENDED = 0, WC_DIFFUSE = 1, WC_SPECULAR = 2, WC_ISO = 3, WC_COUNT = 4, WC_ALL = 0xffffffffu };
 
 struct WfArgs {
     RenderArgs r;       // scene, camera, frame, sample range, chunking (n_chunks, chunk_spp, partial, stamp), statistics
@@ -49,6 +59,7 @@ struct WfArgs {
     uint32_t round;     // parity selects the queues
     uint32_t refill_lanes;  // the walk kernel fetches new rays when this many lanes of a wave are idle
     uint32_t fetch_run;     // ... out of a run of this many queue entries the wave reserves with one atomic
+    uint32_t by_class;      // file the records by class after the intersection stages and shade class by class
 };
 
 // Slots 0 .. capacity - 1 take the first work items, get their camera rays and fill q[0].

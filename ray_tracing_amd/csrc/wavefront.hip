@@ -189,6 +189,7 @@ __global__ __launch_bounds__(64) void wf_prep_kernel(WfArgs a) {
     uint32_t n = *live_count(a, cur, k);
     *live_count(a, cur ^ 1u, k) = 0u;
     a.st.ctl[k * WF_CTL_STRIDE + WF_CTL_CURSOR] = 0u;
+    for (uint32_t c = 0; c < WC_COUNT; ++c) a.st.ctl[k * WF_CTL_STRIDE + WF_CTL_CLASS + c] = 0u;
     const ItemSpace sp = item_space(a.r);
     const unsigned long long spent = __ballot(a.st.ctl[k * WF_CTL_STRIDE + WF_CTL_ITEM] >= item_slots_of(sp, k));
     for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off);
@@ -336,17 +337,48 @@ __global__ __launch_bounds__(256) void wf_finish_kernel(WfArgs a) {
     }
 }
 
-// One level of ray_color after world.hit (renderer.rs:203-235) for every live path, then whatever follows for its
-// slot: the next sample of its item (renderer.rs:100-110), the next item, or nothing more.
-template <uint32_t F, bool PINHOLE>
-__global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(WfArgs a) {
+// Files every record of the round's queue under the class of what its path does next (WC_*): one ballot and prefix
+// count per class and one atomic per wave and class that has members (queue_reserve); the entry is the record's
+// index within its queue lane. A workgroup files the records of its lane under the same lane of the class queues,
+// so the four class lanes together hold exactly what the record lane held.
+__global__ __launch_bounds__(kWfBlock) void wf_classify_kernel(WfArgs a) {
     const uint32_t cur = a.round & 1u, ql = blockIdx.x & (WF_LANES - 1u), first = (blockIdx.x / WF_LANES) * kWfBlock;
     const uint32_t n = *live_count(a, cur, ql);
     if (first >= n) return;
     const bool on = first + threadIdx.x < n;
+    const uint32_t index = on ? first + threadIdx.x : first;
+    const int prim = (int)a.st.q_h[cur][(size_t)ql * a.lane_capacity + index].x;
+    uint32_t cls = WC_ENDED;
+    if (prim >= 0) {
+        const uint32_t mk = a.r.scene.shade[prim].mat_kind;
+        cls = mk == MK_DIFFUSE_LIGHT ? WC_ENDED : (mk == MK_LAMBERTIAN ? WC_DIFFUSE : (mk == MK_ISOTROPIC ? WC_ISO : WC_SPECULAR));
+    }
+    for (uint32_t c = 0; c < WC_COUNT; ++c) {
+        const bool mine = on && cls == c;
+        const uint32_t pos = queue_reserve(mine, a.st.ctl + ql * WF_CTL_STRIDE + WF_CTL_CLASS + c);
+        if (mine) a.st.cls[((size_t)c * WF_LANES + ql) * a.lane_capacity + pos] = index;
+    }
+}
+
+// One level of ray_color after world.hit (renderer.rs:203-235) for every live path, then whatever follows for its
+// slot: the next sample of its item (renderer.rs:100-110), the next item, or nothing more. CLASS = WC_ALL: the
+// records of the round's queue in queue order, whatever they do next. CLASS = one of WC_*: the records filed under
+// that class, and only the code that class runs.
+template <uint32_t F, bool PINHOLE, uint32_t CLASS>
+__global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(WfArgs a) {
+    const uint32_t cur = a.round & 1u, ql = blockIdx.x & (WF_LANES - 1u), first = (blockIdx.x / WF_LANES) * kWfBlock;
+    const uint32_t n = CLASS == WC_ALL ? *live_count(a, cur, ql) : a.st.ctl[ql * WF_CTL_STRIDE + WF_CTL_CLASS + (CLASS & 3u)];
+    if (first >= n) return;
+    const bool on = first + threadIdx.x < n;
     const Tables tb{a.r.scene.prims, a.r.scene.shade, a.r.scene.instances, a.r.scene.light_prims};
     const ItemSpace sp = item_space(a.r);
-    const size_t e = (size_t)ql * a.lane_capacity + (on ? first + threadIdx.x : first);
+    uint32_t index = on ? first + threadIdx.x : first;
+    if (CLASS != WC_ALL) index = a.st.cls[((size_t)(CLASS & 3u) * WF_LANES + ql) * a.lane_capacity + index];
+    const size_t e = (size_t)ql * a.lane_capacity + index;
+    // the scatter code a class can reach: the other materials' branches are compiled out of its kernel
+    constexpr uint32_t FS = CLASS == WC_DIFFUSE ? (F & ~(uint32_t)(F_MAT_METAL | F_MAT_DIELECTRIC | F_MAT_ISOTROPIC))
+                          : CLASS == WC_SPECULAR ? (F & ~(uint32_t)F_MAT_ISOTROPIC)
+                          : CLASS == WC_ISO ? (F & ~(uint32_t)(F_MAT_METAL | F_MAT_DIELECTRIC)) : F;
     PathRegs p;
     float t;
     int prim;
@@ -410,17 +442,17 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(WfArgs a) {
     Rng g;
     g.init_with_block0(p.pixel, p.sample, r_bounce, r_stream, a.r.seed, w0, w1, w2, w3);
     bool restart = false;  // closed by its scatter: the sample is complete and the slot needs a camera ray from a fresh stream
-    if (alive && !ended) {
-        const bool cont = scatter<F>(a.r.scene, tb, m, h, g, p.ray, p.thr);
+    if (CLASS != WC_ENDED && alive && !ended) {
+        const bool cont = scatter<FS>(a.r.scene, tb, m, h, g, p.ray, p.thr);
         ++p.bounce;
         if (!cont || p.bounce == a.r.max_depth) {  // absorbed, or renderer.rs:198-200: the next level returns 0
             ++p.sample;
             restart = true;
         }
-    } else if (alive) {
+    } else if ((CLASS == WC_ALL || CLASS == WC_ENDED) && alive) {
         begin_sample<PINHOLE>(a.r, p, g);
     }
-    if (__ballot(restart) != 0) {
+    if (CLASS != WC_ENDED && __ballot(restart) != 0) {
         const bool done = restart && p.sample == p.sample_end;
         if (__ballot(done) != 0) {
             if (done) store_item(a.r, p);
@@ -506,8 +538,30 @@ static hipError_t launch_round(const WfArgs& a, hipStream_t stream) {
                                stream, a);
         }
     }
-    if (is_pinhole(a)) hipLaunchKernelGGL((wf_shade_kernel<F, true>), pool, block, 0, stream, a);
-    else hipLaunchKernelGGL((wf_shade_kernel<F, false>), pool, block, 0, stream, a);
+    const bool pin = is_pinhole(a);
+    if (!a.by_class) {
+        if (pin) hipLaunchKernelGGL((wf_shade_kernel<F, true, WC_ALL>), pool, block, 0, stream, a);
+        else hipLaunchKernelGGL((wf_shade_kernel<F, false, WC_ALL>), pool, block, 0, stream, a);
+        return hipGetLastError();
+    }
+    // one shading launch per class the scene's materials can produce; every launch covers the pool (a workgroup whose
+    // part of its class lane is empty returns at once) and all of them append to the next round's queue
+    hipLaunchKernelGGL(wf_classify_kernel, pool, block, 0, stream, a);
+    const uint32_t f = a.r.scene.features;
+#define MIRT_SHADE_CLASS(C)                                                                              \
+    do {                                                                                                 \
+        if (pin) hipLaunchKernelGGL((wf_shade_kernel<F, true, C>), pool, block, 0, stream, a);           \
+        else hipLaunchKernelGGL((wf_shade_kernel<F, false, C>), pool, block, 0, stream, a);              \
+    } while (0)
+    MIRT_SHADE_CLASS(WC_ENDED);
+    MIRT_SHADE_CLASS(WC_DIFFUSE);
+    if constexpr ((F & (F_MAT_METAL | F_MAT_DIELECTRIC)) != 0) {
+        if (f & (F_MAT_METAL | F_MAT_DIELECTRIC)) MIRT_SHADE_CLASS(WC_SPECULAR);
+    }
+    if constexpr ((F & F_MAT_ISOTROPIC) != 0) {
+        if (f & F_MAT_ISOTROPIC) MIRT_SHADE_CLASS(WC_ISO);
+    }
+#undef MIRT_SHADE_CLASS
     return hipGetLastError();
 }
 

@@ -28,10 +28,11 @@ def main():
     ap.add_argument("--depth", type=int)
     ap.add_argument("--spp", type=int)
     ap.add_argument("--reps", type=int, default=3)
-    ap.add_argument("--kernel", default="queue", choices=["queue", "fused", "wavefront", "auto"])
+    ap.add_argument("--kernel", default="queue", choices=["queue", "fused", "wavefront", "wavefront_classes", "auto"])
     ap.add_argument("cases", nargs="+")
     args = ap.parse_args()
-    kern = {"queue": rt.KERNEL_QUEUE, "fused": rt.KERNEL_FUSED, "wavefront": rt.KERNEL_WAVEFRONT, "auto": rt.KERNEL_AUTO}[args.kernel]
+    kern = {"queue": rt.KERNEL_QUEUE, "fused": rt.KERNEL_FUSED, "wavefront": rt.KERNEL_WAVEFRONT, "wavefront_classes": rt.KERNEL_WAVEFRONT | rt.KERNEL_WF_CLASSES,
+            "auto": rt.KERNEL_AUTO}[args.kernel]
     tag = os.path.basename(os.environ.get("MIRT_LIB", "libmirt.so"))
     for case in args.cases:
         scene, W, H, spp, depth, kw = CASES[case]
@@ -49,7 +50,7 @@ def main():
             st = ctx.stats()
             if rep:
                 best = max(best, st["samples"] / st["kernel_ms"] / 1e3)
-        print(f"{tag:18s} {case:11s} {W}x{H} spp={spp} depth={depth} seg/sample={st['segments'] / st['samples']:.3f} "
+        print(f"{tag:18s} {args.kernel:17s} {case:11s} {W}x{H} spp={spp} depth={depth} seg/sample={st['segments'] / st['samples']:.3f} "
               f"loop occupancy {st['segments'] / max(st['lane_slots'], 1):.3f}  {best:8.0f} Msamples/s", flush=True)
 
 
