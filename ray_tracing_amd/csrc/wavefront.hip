@@ -475,7 +475,8 @@ __global__ __launch_bounds__(kWfBlock) void wf_shade_kernel(WfArgs a) {
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kVariantBox = F_SPHERE | F_RECT | F_INSTANCE | F_MAT_DIELECTRIC | F_MAT_LIGHT | F_MAT_METAL;
 constexpr uint32_t kVariantSmoke = kVariantBox | F_MEDIUM | F_MAT_ISOTROPIC;
-constexpr uint32_t kVariantSpheres = F_SPHERE | F_MOVING | F_BVH | F_TEX_CHECKER | F_MAT_METAL | F_MAT_DIELECTRIC | F_MAT_LIGHT | F_RECT;
+constexpr uint32_t kVariantSpheresOnly = F_SPHERE | F_MOVING | F_BVH | F_TEX_CHECKER | F_MAT_METAL | F_MAT_DIELECTRIC | F_MAT_LIGHT;
+constexpr uint32_t kVariantSpheres = kVariantSpheresOnly | F_RECT;
 
 static bool is_pinhole(const WfArgs& a) { return a.r.cam.lens_radius == 0.f && !(a.r.scene.features & F_MOVING); }
 
@@ -569,6 +570,7 @@ hipError_t wf_launch_round(const WfArgs& a, hipStream_t stream) {
     const uint32_t f = a.r.scene.features;
     if ((f & ~kVariantBox) == 0) return launch_round<kVariantBox>(a, stream);
     if ((f & ~kVariantSmoke) == 0) return launch_round<kVariantSmoke>(a, stream);
+    if ((f & ~kVariantSpheresOnly) == 0) return launch_round<kVariantSpheresOnly>(a, stream);
     if ((f & ~kVariantSpheres) == 0) return launch_round<kVariantSpheres>(a, stream);
     return launch_round<F_ALL>(a, stream);
 }

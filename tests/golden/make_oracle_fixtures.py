@@ -1,5 +1,6 @@
 """Generates the oracle-made golden vectors under tests/golden/ (run from the repository root:
-`python tests/golden/make_oracle_fixtures.py`; `... converged final` remakes one converged image only). The reference ships no fixtures and cannot be built in
+`python tests/golden/make_oracle_fixtures.py`; `... converged final` remakes one converged image only, `... first_hits`
+only the first-hit grids). The reference ships no fixtures and cannot be built in
 this environment, so these vectors come from the CPU oracle (oracle/), which is itself pinned only by
 the analytic Cornell known answers, the Philox known answers and the sampler properties — they freeze the
 oracle's behaviour so that a later change of the oracle or of the device code shows up against fixed
@@ -45,6 +46,8 @@ def main():
                             t=t.reshape(FH, FW))
         print(name, "first hits:", int((ids >= 0).sum()), "of", ids.size, flush=True)
     for name, spp in CONVERGED.items():
+        if len(sys.argv) > 1 and sys.argv[1] == "first_hits":
+            break
         if only and name not in only:
             continue
         t0 = time.time()
