@@ -277,4 +277,41 @@ inline uint32_t collapse_to_four(const std::vector<DevBvhNode>& nodes2, uint32_t
     return root4;
 }
 
+// Renumbers the four-wide nodes of all hierarchies breadth first from their roots together (all roots, then all their
+// interior children, level by level), so that the nodes nearest the roots — the ones every walk visits — are the
+// first of the array, whatever number of hierarchies the scene has: a kernel can hold nodes [0, k) in LDS and tell by
+// the index alone where a node lives. References inside the nodes and the roots are rewritten; leaf references and
+// everything else stay. `roots` are the hierarchies' root indices, in world order.
+inline void order_nodes_breadth_first(std::vector<DevBvhNode4>& nodes, std::vector<uint32_t*>& roots) {
+    const uint32_t none = 0xffffffffu;
+    std::vector<uint32_t> order, new_index(nodes.size(), none);
+    order.reserve(nodes.size());
+    for (uint32_t* r : roots) {
+        if (new_index[*r] != none) continue;
+        new_index[*r] = (uint32_t)order.size();
+        order.push_back(*r);
+    }
+    for (size_t head = 0; head < order.size(); ++head) {
+        const DevBvhNode4& nd = nodes[order[head]];
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t ref = nd.ref[c];
+            if (ref == none || (ref & 0x80000000u) || new_index[ref] != none) continue;
+            new_index[ref] = (uint32_t)order.size();
+            order.push_back(ref);
+        }
+    }
+    // (nodes no root reaches cannot exist; they would keep their place behind the others)
+    for (uint32_t i = 0; i < nodes.size(); ++i)
+        if (new_index[i] == none) { new_index[i] = (uint32_t)order.size(); order.push_back(i); }
+    std::vector<DevBvhNode4> out(nodes.size());
+    for (uint32_t i = 0; i < nodes.size(); ++i) {
+        DevBvhNode4 nd = nodes[i];
+        for (int c = 0; c < 4; ++c)
+            if (nd.ref[c] != none && !(nd.ref[c] & 0x80000000u)) nd.ref[c] = new_index[nd.ref[c]];
+        out[new_index[i]] = nd;
+    }
+    for (uint32_t* r : roots) *r = new_index[*r];
+    nodes.swap(out);
+}
+
 }  // namespace mirt

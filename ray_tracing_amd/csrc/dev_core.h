@@ -634,7 +634,12 @@ MIRT_DEV void walk_push(Walk& w, uint32_t* stack, uint32_t stride, bool on, uint
     stack[w.sp * stride] = ref;
     w.sp += on ? 1u : 0u;
 }
-MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w, uint32_t* stack, uint32_t stride, uint32_t* wave_cost) {
+// `top`: the workgroup's LDS copy of nodes [0, s.lds_nodes), kLdsNodeStride bytes apart, or nullptr. The array is
+// ordered breadth first, so these are the nodes nearest the roots; a lane whose node is among them reads it from LDS
+// and leaves the vector L1 — whose throughput, at 112 bytes per lane and step, bounds the walks of large trees beside
+// instruction issue — to the lanes deeper down.
+MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w, uint32_t* stack, uint32_t stride, uint32_t* wave_cost,
+                        const uint32_t* top) {
     // Byte offset of the entry quad inside an axis' pair of quads: 0 (low planes) where the ray ascends, 16 (high
     // planes) where it descends. Invariant over the walk: the compiler keeps the three values across the node loop.
     // (A reciprocal of -0 was limited to -2^100 by walk_ray: its sign picks the high planes, and the products say the
@@ -643,10 +648,20 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w,
     const char* const nodes = reinterpret_cast<const char*>(s.bvh_nodes);
     const uint32_t at = w.ref << 7;  // byte offset of the node: the upload refuses more than 2^25 nodes
     const uint32_t ax = at | sx, ay = (at | sy) + 32u, az = (at | sz) + 64u;
-    const float4 px = *reinterpret_cast<const float4*>(nodes + ax), qx = *reinterpret_cast<const float4*>(nodes + (ax ^ 16u));
-    const float4 py = *reinterpret_cast<const float4*>(nodes + ay), qy = *reinterpret_cast<const float4*>(nodes + (ay ^ 16u));
-    const float4 pz = *reinterpret_cast<const float4*>(nodes + az), qz = *reinterpret_cast<const float4*>(nodes + (az ^ 16u));
-    const uint4 refs = *reinterpret_cast<const uint4*>(nodes + at + 96u);
+    float4 px, qx, py, qy, pz, qz;
+    uint4 refs;
+    if (top && w.ref < s.lds_nodes) {
+        const char* const n = reinterpret_cast<const char*>(top) + w.ref * kLdsNodeStride;
+        px = *reinterpret_cast<const float4*>(n + sx); qx = *reinterpret_cast<const float4*>(n + (sx ^ 16u));
+        py = *reinterpret_cast<const float4*>(n + 32u + sy); qy = *reinterpret_cast<const float4*>(n + 32u + (sy ^ 16u));
+        pz = *reinterpret_cast<const float4*>(n + 64u + sz); qz = *reinterpret_cast<const float4*>(n + 64u + (sz ^ 16u));
+        refs = *reinterpret_cast<const uint4*>(n + 96u);
+    } else {
+        px = *reinterpret_cast<const float4*>(nodes + ax); qx = *reinterpret_cast<const float4*>(nodes + (ax ^ 16u));
+        py = *reinterpret_cast<const float4*>(nodes + ay); qy = *reinterpret_cast<const float4*>(nodes + (ay ^ 16u));
+        pz = *reinterpret_cast<const float4*>(nodes + az); qz = *reinterpret_cast<const float4*>(nodes + (az ^ 16u));
+        refs = *reinterpret_cast<const uint4*>(nodes + at + 96u);
+    }
     // a counting launch (wave-uniform) tallies the child boxes the node really has: its first two, and the
     // third and fourth where they exist
     if (wave_cost) atomicAdd(wave_cost + 3, 2u + (refs.z != kWalkIdle ? 1u : 0u) + (refs.w != kWalkIdle ? 1u : 0u));
@@ -736,7 +751,7 @@ MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w,
 
 // Walk every hierarchy of the scene to the end.
 template <uint32_t F>
-MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t* stack, uint32_t stride) {
+MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t* stack, uint32_t stride, const uint32_t* top = nullptr) {
     const uint32_t n = walk_count(s, r);
     w.next = 0;
     w.ref = kWalkIdle;
@@ -748,7 +763,7 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
         // descend through interior nodes until each of them holds a leaf (or is done), then all
         // intersect their leaves together, so the long leaf code runs with many lanes active.
         while (w.ref != kWalkIdle) {
-            while (ref_is_node(w.ref)) walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride, nullptr);
+            while (ref_is_node(w.ref)) walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride, nullptr, top);
             if (ref_is_leaf(w.ref)) walk_leaf<F>(s, t_min, lr, w, stack, stride, tally);
         }
     }
@@ -767,7 +782,8 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
 // `steps` receives the number of steps taken (statistics builds read it; otherwise it folds away).
 template <uint32_t F>
 MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t min_lanes,
-                        uint32_t node_lanes, uint32_t* stack, uint32_t stride, uint32_t& steps, uint32_t* wave_cost) {
+                        uint32_t node_lanes, uint32_t* stack, uint32_t stride, uint32_t& steps, uint32_t* wave_cost,
+                        const uint32_t* top = nullptr) {
     steps = 0;
     uint32_t tally = 0, tallied_steps = 0;
     // (a counting launch only) the lane's tally goes to the wave's words: at the end of the turn, and whenever its
@@ -785,7 +801,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
         if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w, lr);
         while (w.ref != kWalkIdle && steps < budget) {
             while (ref_is_node(w.ref) && steps < budget) {
-                walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride, wave_cost);
+                walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride, wave_cost, top);
                 ++steps;
                 if ((uint32_t)__popcll(__ballot(ref_is_node(w.ref))) < node_lanes) break;
             }

@@ -189,7 +189,14 @@ struct DevScene {
     // are launched with that many levels; a test may lower it to see the overflow report).
     uint32_t* fault;
     uint32_t stack_limit;
+    // Nodes [0, lds_nodes) of bvh_nodes are also held in the workgroup's LDS (set by the launch of a kernel that copies
+    // them there; 0 everywhere else): the array is ordered breadth first from the roots, so these are the nodes
+    // nearest the roots, which every walk visits.
+    uint32_t lds_nodes;
 };
+// A node in LDS takes kLdsNodeStride bytes, 16 more than its 128: with a stride of 128 every node would start in the
+// same bank and the lanes of a wave, each reading the same quad of a different node, would all meet in four banks.
+constexpr uint32_t kLdsNodeStride = 144;
 enum : uint32_t {
     FAULT_STACK_OVERFLOW = 1u,  // a walk pushed beyond its stack: the children that did not fit were dropped
     FAULT_STALE_CHUNK = 2u,     // a (pixel, chunk) slot did not carry the stamp of its launch: its item was never stored

@@ -287,7 +287,10 @@ __device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* co
     return got;
 }
 
-template <uint32_t F, bool LDS_TABLES, bool PINHOLE>
+// TOP_NODES: the hierarchies' nodes nearest the roots are copied to LDS behind the stacks and fetched from there
+// (walk_node). Launched only where most of the scene's nodes fit (launch_persistent): the second fetch path in the
+// node step costs 2-4 % by itself and pays when few steps need it.
+template <uint32_t F, bool LDS_TABLES, bool PINHOLE, bool TOP_NODES = false>
 __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(RenderArgs a) {
     // the LDS-table variants are only launched for scenes without a hierarchy: no traversal code, no stack
     constexpr uint32_t FT = LDS_TABLES ? (F & ~(uint32_t)F_BVH) : F;
@@ -355,6 +358,16 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     uint32_t* const wave_words = s_walk_cost + ((FT & F_BVH) ? (threadIdx.x >> 6) * 4u : 0u);
     if ((FT & F_BVH) && (threadIdx.x & 63u) == 0u) wave_words[0] = wave_words[1] = wave_words[2] = wave_words[3] = 0u;
     uint32_t* const wave_cost = a.count_cost ? wave_words : nullptr;  // only a counting launch tallies (walk_some)
+    // the hierarchies' nodes nearest the roots, copied behind the stacks (walk_node)
+    const uint32_t* top = nullptr;
+    if constexpr ((FT & F_BVH) != 0 && TOP_NODES) {
+        uint32_t* const dst = bvh_stack + (a.scene.stack_limit + kBvhStackSlack) * kBlock;
+        const uint32_t* const src = reinterpret_cast<const uint32_t*>(a.scene.bvh_nodes);
+        constexpr uint32_t kNodeWords = (uint32_t)sizeof(DevBvhNode4) / 4u, kStrideWords = kLdsNodeStride / 4u;
+        for (uint32_t i = threadIdx.x; i < a.scene.lds_nodes * kNodeWords; i += kBlock) dst[(i / kNodeWords) * kStrideWords + (i % kNodeWords)] = src[i];
+        __syncthreads();
+        top = dst;
+    }
     MIRT_STATS(const long long t_birth = clock64(); long long ph0 = 0, ph1 = 0, ph2 = 0);
     Walk wk;               // the lane's walk of the hierarchies, kept from iteration to iteration
     bool walking = false;  // ... which is not over yet
@@ -455,7 +468,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
             const uint32_t live = (uint32_t)__popcll(__ballot(alive));
             if (alive && !closed)
                 walking = !walk_some<FT>(scene_now(), ray, 0.001f, wk, walk_n, walk_budget, (walk_min_lanes * live) >> 6,
-                                         (walk_node_lanes * live) >> 6, stack, kBlock, wsteps, wave_cost);
+                                         (walk_node_lanes * live) >> 6, stack, kBlock, wsteps, wave_cost, top);
             MIRT_STATS(tc2 = clock64());
             MIRT_STATS(walk_histogram(alive, wsteps));
             ready = alive && !walking;
@@ -687,20 +700,43 @@ static uint32_t stack_bytes(const DevScene& s) {
     return (s.features & F_BVH) ? (s.stack_limit + kBvhStackSlack) * kBlock * (uint32_t)sizeof(uint32_t) : 0u;
 }
 
-template <class Kernel>
-static hipError_t launch_persistent(Kernel kernel, const RenderArgs& a, hipStream_t stream) {
+// `kernel_top` (may be the same as `kernel`): the TOP_NODES form of the kernel, launched instead when at least half of
+// the scene's hierarchy nodes fit into the LDS the resident workgroups leave free.
+template <class Kernel, class KernelTop>
+static hipError_t launch_persistent(Kernel kernel, KernelTop kernel_top, const RenderArgs& a_in, hipStream_t stream) {
     int device = 0, cus = 0, per_cu = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
+    RenderArgs a = a_in;
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, stack_bytes(a.scene))) != hipSuccess) return e;
+    // Nodes of the hierarchies kept in LDS behind the stacks: as many as fit without costing a resident workgroup
+    // (a.scene.lds_nodes arrives as the number of nodes the scene has).
+    uint32_t lds_nodes = 0;
+    // (not for a launch of under 4 M samples — under a millisecond: there the copy into LDS is what shows)
+    const bool long_launch = (uint64_t)a.width * a.height * a.spp_count >= (4ull << 20);
+    if ((void*)kernel_top != (void*)kernel && (a.scene.features & F_BVH) && per_cu > 0 && long_launch) {
+        int lds_cu = 0, with_nodes = 0;
+        if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, device) != hipSuccess) lds_cu = 0;
+        const long room = std::min<long>((long)lds_cu / per_cu, 65536l) - (long)stack_bytes(a.scene) - 2048l;  // (the kernel's own few words, and slack)
+        if (room > 0) lds_nodes = (uint32_t)std::min<long>(room / (long)kLdsNodeStride, (long)a.scene.lds_nodes);
+        static const long lds_env = [] { const char* ev = std::getenv("MIRT_LDS_NODES"); return ev ? std::atol(ev) : -1l; }();
+        if (lds_env >= 0) lds_nodes = std::min(lds_nodes, (uint32_t)lds_env);
+        else if (2u * lds_nodes < a.scene.lds_nodes) lds_nodes = 0;
+        if (lds_nodes && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with_nodes, kernel_top, kBlock, stack_bytes(a.scene) + lds_nodes * kLdsNodeStride) != hipSuccess ||
+                          with_nodes < per_cu))
+            lds_nodes = 0;
+    }
+    a.scene.lds_nodes = lds_nodes;
+    const size_t lds_bytes = stack_bytes(a.scene) + (size_t)lds_nodes * kLdsNodeStride;
     const uint64_t items = (uint64_t)((a.width + 7u) / 8u) * ((a.height + 7u) / 8u) * 64u * a.n_chunks;
     if (a.n_chunks == 0 || items >= 0xffffff00ull || (uint64_t)a.n_chunks * a.width * a.height >= 0xffffffffull ||
         (a.n_chunks > 1 && !a.partial))
         return hipErrorInvalidValue;
     const uint32_t want = (uint32_t)((items + kBlock - 1) / kBlock);
     const uint32_t resident = (uint32_t)std::max(cus * per_cu, 1);
-    hipLaunchKernelGGL(kernel, dim3(std::min(want, resident)), dim3(kBlock), stack_bytes(a.scene), stream, a);
+    if (lds_nodes) hipLaunchKernelGGL(kernel_top, dim3(std::min(want, resident)), dim3(kBlock), lds_bytes, stream, a);
+    else hipLaunchKernelGGL(kernel, dim3(std::min(want, resident)), dim3(kBlock), lds_bytes, stream, a);
     if ((e = hipGetLastError()) != hipSuccess || a.n_chunks == 1) return e;
     return launch_reduce_chunks(a, stream);
 }
@@ -724,10 +760,14 @@ struct RenderLauncher {
                 return hipGetLastError();
             }
             const bool lq = lds && !(s.features & F_BVH);  // the LDS-table variants carry no traversal stack
-            if (lq && pinhole) return launch_persistent(render_queue_kernel<F, true, true>, a, stream);
-            if (lq) return launch_persistent(render_queue_kernel<F, true, false>, a, stream);
-            if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, a, stream);
-            return launch_persistent(render_queue_kernel<F, false, false>, a, stream);
+            if (lq && pinhole) return launch_persistent(render_queue_kernel<F, true, true>, render_queue_kernel<F, true, true>, a, stream);
+            if (lq) return launch_persistent(render_queue_kernel<F, true, false>, render_queue_kernel<F, true, false>, a, stream);
+            if constexpr ((F & F_BVH) != 0) {
+                if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true, true>, a, stream);
+                return launch_persistent(render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false, true>, a, stream);
+            }
+            if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true>, a, stream);
+            return launch_persistent(render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false>, a, stream);
         }
         if (lds && pinhole) hipLaunchKernelGGL((render_fused_kernel<F, true, true>), grid, block, stack_bytes(s), stream, a);
         else if (lds) hipLaunchKernelGGL((render_fused_kernel<F, true, false>), grid, block, stack_bytes(s), stream, a);

@@ -513,6 +513,14 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
         }
         entries[e] = q;
     }
+    // nodes of all hierarchies renumbered breadth first from the roots: the most visited ones first (kernels keep the
+    // first few in LDS)
+    {
+        std::vector<uint32_t*> roots;
+        for (DevEntry& q : entries)
+            if (q.kind == EK_BVH) roots.push_back(&q.bvh_root);
+        if (!roots.empty()) order_nodes_breadth_first(nodes, roots);
+    }
     // leaf records of the hierarchies, in tree order (a leaf reference holds a 27-bit record index)
     if (slots.size() >= (1u << 27) - 1u) return bad("too many hierarchy members");
     if (nodes.size() >= (1u << 25)) return bad("too many hierarchy nodes (a walk addresses a node by a 32-bit byte offset: at most 2^25 nodes of 128 bytes)");
@@ -587,6 +595,7 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     for (int a = 0; a < 3; ++a) s.background[a] = d->background[a];
     s.fault = fault_word(c);
     s.stack_limit = stack_need;   // what the deepest walk can need: the kernels' LDS stacks are launched this deep
+    s.lds_nodes = (uint32_t)nodes.size();  // nodes there are; the persistent kernel's launch keeps as many in LDS as fit
     // (the test build of the library lets a test lower the limit to see the overflow report of walk_node)
 #ifdef MIRT_DEBUG_HOOKS
     static const long stack_env = [] { const char* e = std::getenv("MIRT_DEBUG_STACK_LIMIT"); return e ? std::atol(e) : -1l; }();

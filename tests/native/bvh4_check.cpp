@@ -88,6 +88,30 @@ static void run_case(const char* name, std::vector<BuildObject> objs, uint32_t p
     CHECK(need <= (uint32_t)kBvhStackMax, "need %u beyond the launch limit", need);
     CHECK(builder.deepest_leaf() - 1 <= kBvhStackDepth, "binary depth %d", builder.deepest_leaf());
     for (size_t i = 0; i < seen.size(); ++i) CHECK(seen[i] == 1, "object %zu is in %d leaves", i, seen[i]);
+    // breadth-first renumbering together with a second, one-node tree (the three placeholder nodes in front become
+    // it): the same checks hold from the new root, both roots lead the array, and a node's interior children never
+    // come before it
+    {
+        nodes[0] = DevBvhNode4{};
+        for (int c = 0; c < 4; ++c) nodes[0].ref[c] = 0xffffffffu;
+        nodes[0].ref[0] = 0x80000000u;  // one leaf
+        uint32_t other_root = 0, root = root4;
+        std::vector<uint32_t*> roots{&other_root, &root};
+        std::vector<DevBvhNode4> ordered(nodes.begin(), nodes.end());
+        ordered[1] = ordered[2] = ordered[0];  // unreachable placeholders keep a place behind the others
+        order_nodes_breadth_first(ordered, roots);
+        CHECK(other_root == 0 && root == 1, "roots after renumbering: %u %u", other_root, root);
+        for (uint32_t i = 0; i < ordered.size(); ++i)
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t ref = ordered[i].ref[c];
+                if (ref != 0xffffffffu && !(ref & 0x80000000u)) CHECK(ref > i && ref < ordered.size(), "node %u child %u out of order", i, ref);
+            }
+        std::vector<int> seen2(boxes.size(), 0);
+        Box all2;
+        const uint32_t walked2 = check_node(ordered, root, slots, ppo, boxes, seen2, &all2, 0);
+        CHECK(walked2 == need, "need after renumbering %u", walked2);
+        for (size_t i = 0; i < seen2.size(); ++i) CHECK(seen2[i] == 1, "after renumbering object %zu is in %d leaves", i, seen2[i]);
+    }
     std::printf("%-28s objects %7zu  binary nodes %7zu  deepest leaf %2d  four-wide nodes %7zu  stack need %2u\n", name, boxes.size(),
                 binary.size(), builder.deepest_leaf(), nodes.size() - 3, need);
 }
