@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (on the GPU box, from the repository root): scripts/r2_profile.sh <tag> <config> [steps] [extra bench args...]
+# usage (on the GPU box, from the repository root): scripts/profile_config.sh <tag> <config> [steps] [extra bench args...]
 # rocprofv3 evidence for one bench.py configuration: a --kernel-trace --stats pass of the bench command itself, then
 # separate --pmc passes (instruction mix and lane activity, HBM traffic) of the same command with few steps.
 # Everything lands under gpurun_out/prof_<tag>/; the summaries that are kept get copied to profiles/ by hand.
@@ -38,6 +38,14 @@ with open(out + "/pmc_summary.txt", "w") as o:
         a = tot.get((kern, "SQ_ACTIVE_INST_VALU"))
         if v and t:
             o.write(f"{kern} lanes active per VALU instruction = SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU) = {t / (64 * v):.4f}\n")
+        g, ng = tot.get((kern, "GRBM_GUI_ACTIVE")), rows.get((kern, "GRBM_GUI_ACTIVE"))
+        nv = rows.get((kern, "SQ_INSTS_VALU"))
+        if v and g and ng and nv:
+            # clocks per vector instruction and SIMD: device clocks of a dispatch x 1024 SIMDs / its wave-level vector
+            # instructions. The counter comes back summed over the 8 XCDs (a 127.6 ms launch reads 2.435e9 = 8 x 127.6 ms
+            # x 2.385 GHz), hence the division by 8.
+            o.write(f"{kern} clocks per VALU instruction and SIMD = (GRBM_GUI_ACTIVE / 8 XCDs) x 1024 SIMDs / SQ_INSTS_VALU (per dispatch) = {(g / ng / 8) * 1024 / (v / nv):.3f}\n")
+            o.write(f"{kern} VALU instructions per dispatch = {v / nv:.4g}\n")
         f_, w_ = tot.get((kern, "FETCH_SIZE")), tot.get((kern, "WRITE_SIZE"))
         n = rows.get((kern, "FETCH_SIZE"))
         if f_ is not None and w_ is not None and n:
