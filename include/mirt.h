@@ -152,6 +152,12 @@ enum { MIRT_KERNEL_AUTO = 0, MIRT_KERNEL_FUSED = 1, MIRT_KERNEL_WAVEFRONT = 2, M
  * class of what they do next — the ScatterType of material.rs:19-23 (Diffuse, Specular, ISO) and the paths that end
  * (miss, emitter) — and the shading stage runs once per class. Same samples, same sums. */
 #define MIRT_KERNEL_WF_CLASSES 0x200u
+/* OR-ed into MIRT_KERNEL_AUTO / MIRT_KERNEL_QUEUE: in scenes with hierarchies the persistent kernel pools the walks of
+ * a workgroup's 256 lanes in LDS and its four waves advance them together — one step per ray and round, the rays that
+ * need a node step in one list, those that need a leaf test in another, 64 of a kind per wave — instead of every lane
+ * walking its own ray (aabb.rs:112-126 is the step either way). Same walks, same samples, same sums. Ignored by
+ * scenes without a hierarchy and by launches that carry MIRT_KERNEL_COUNT_WALKS. */
+#define MIRT_KERNEL_POOL 0x400u
 
 typedef struct mirt_render_params {
     uint32_t width, height;
@@ -191,6 +197,7 @@ typedef struct mirt_stats {
 } mirt_stats;
 #define MIRT_FAULT_STACK_OVERFLOW 1u /* a hierarchy walk found its traversal stack full and dropped a subtree */
 #define MIRT_FAULT_STALE_CHUNK 2u    /* a (pixel, sample chunk) work item of the persistent kernel was never stored */
+#define MIRT_FAULT_POOL_STALL 4u     /* a workgroup of the pooled-walk form gave up after 2^20 iterations (a ray lost in its pool) */
 
 /* ---- entry points --------------------------------------------------------------------------- */
 

@@ -19,6 +19,7 @@ ASSETS = os.path.join(_HERE, "assets")
 MIRT_OK = 0
 KERNEL_AUTO, KERNEL_FUSED, KERNEL_WAVEFRONT, KERNEL_QUEUE = 0, 1, 2, 3
 KERNEL_WF_CLASSES = 0x200    # OR-ed into KERNEL_WAVEFRONT: one queue per class of what a path does next, shading class by class
+KERNEL_POOL = 0x400          # OR-ed into KERNEL_AUTO / KERNEL_QUEUE: a workgroup's hierarchy walks pooled in LDS, advanced by its waves together
 KERNEL_COUNT_WALKS = 0x100   # OR-ed into a kernel selector: also tally the hierarchy walks (stats bvh_*), a few percent slower
 
 # every symbol include/mirt.h and include/mirt_host.h declare

@@ -200,6 +200,7 @@ constexpr uint32_t kLdsNodeStride = 144;
 enum : uint32_t {
     FAULT_STACK_OVERFLOW = 1u,  // a walk pushed beyond its stack: the children that did not fit were dropped
     FAULT_STALE_CHUNK = 2u,     // a (pixel, chunk) slot did not carry the stamp of its launch: its item was never stored
+    FAULT_POOL_STALL = 4u,      // a workgroup of the pooled-walk kernel gave up after 2^20 iterations: a ray was lost in its pool
 };
 
 }  // namespace mirt

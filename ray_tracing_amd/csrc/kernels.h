@@ -20,6 +20,10 @@ struct RenderArgs {
     // through interior nodes pauses for a leaf round when fewer than walk_node_lanes lanes are still descending.
     // A lane whose walk is not over continues in the next iteration.
     uint32_t walk_budget, walk_min_lanes, walk_node_lanes;
+    // pool != 0: the hierarchy walks of a workgroup are pooled in LDS and advanced by its four waves together, in rounds
+    // of one step per ray (dev_pool.h); the rounds of an iteration stop when fewer than pool_stop rays are left.
+    // pool_steps: node steps a lane takes on its ray per round while the ray keeps descending (1 = one step per round).
+    uint32_t pool, pool_stop, pool_steps;
     // The persistent kernel's work items are (pixel, chunk of chunk_spp samples): n_chunks per pixel. With
     // more than one chunk the item sums go to partial[chunk * width * height + pixel] and are added to
     // accum in chunk order by a second kernel.

@@ -17,6 +17,7 @@
 #include <mutex>
 #include "kernels.h"
 #include "dev_core.h"
+#include "dev_pool.h"
 
 namespace mirt {
 
@@ -290,8 +291,10 @@ __device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* co
 // TOP_NODES: the hierarchies' nodes nearest the roots are copied to LDS behind the stacks and fetched from there
 // (walk_node). Launched only where most of the scene's nodes fit (launch_persistent): the second fetch path in the
 // node step costs 2-4 % by itself and pays when few steps need it.
-template <uint32_t F, bool LDS_TABLES, bool PINHOLE, bool TOP_NODES = false>
+// POOL: the hierarchy walks of the workgroup's 256 lanes advance together in LDS (dev_pool.h) instead of lane by lane.
+template <uint32_t F, bool LDS_TABLES, bool PINHOLE, bool TOP_NODES = false, bool POOL = false>
 __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(RenderArgs a) {
+    static_assert(!POOL || (!LDS_TABLES && !TOP_NODES && (F & F_BVH) != 0), "the pooled walk is a form of the hierarchy variants");
     // the LDS-table variants are only launched for scenes without a hierarchy: no traversal code, no stack
     constexpr uint32_t FT = LDS_TABLES ? (F & ~(uint32_t)F_BVH) : F;
     extern __shared__ uint32_t bvh_stack[];  // [scene.stack_limit + kBvhStackSlack][kBlock], sized at the launch
@@ -376,6 +379,15 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     const uint32_t walk_budget = a.walk_budget, walk_min_lanes = a.walk_min_lanes, walk_node_lanes = a.walk_node_lanes;
     wk.ref = kWalkIdle;
     wk.next = wk.sp = 0;
+    // the workgroup's pool of walks, behind the stacks (POOL form)
+    Pool pool{};
+    PoolState pool_state{0u, 0u, 0u, 0u, 0u};
+    if constexpr (POOL) {
+        pool = pool_at(bvh_stack + (a.scene.stack_limit + kBvhStackSlack) * kBlock);
+        pool_clear(pool);
+        __syncthreads();
+    }
+    const uint32_t pool_stop = a.pool_stop, pool_steps = a.pool_steps;
 
     // Gives the lanes with `need` their next pixel: position, first sample, empty sums. Indices of the edge
     // tiles that lie outside the frame are skipped. A lane that gets none is done (alive = false).
@@ -442,7 +454,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         g.init(pixel, sample, 0u, STREAM_CAMERA, a.seed);
         ray = camera_ray<PINHOLE>(cam_now(), xy & 0xffffu, xy >> 16, a.width, a.height, jitter, g);
     }
-    while (__ballot(alive) != 0) {
+    while (POOL || __ballot(alive) != 0) {
         ++rounds;
         // ---- trace: scene.world.hit (renderer.rs:201). The lists are scanned in the iteration that starts
         //      the segment; the hierarchies are walked a bounded number of steps per iteration, and a lane
@@ -451,7 +463,35 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         int prim = -1;
         bool ready = alive;
         MIRT_STATS(const long long tc0 = clock64(); long long tc1 = tc0, tc2 = tc0);
-        if constexpr ((FT & F_BVH) != 0) {
+        if constexpr ((FT & F_BVH) != 0 && POOL) {
+            // The lanes that start a segment scan the lists and hand their ray to the workgroup's pool; then all four
+            // waves advance the pool's walks together, round by round (dev_pool.h). A lane whose ray is not through
+            // when the rounds stop keeps waiting (walking) and sits out the rest of the iteration.
+            const bool start = alive && !walking && !closed;
+            bool submit = false;
+            if (start) {
+                DrawKey key{pixel, sample, bounce, a.seed};
+                wk.closest = MIRT_INF;
+                wk.best = -1;
+                world_lists<FT>(scene_now(), ray, key, wk.closest, wk.best);
+                submit = walk_count(scene_now(), ray) != 0u;
+            }
+            segments += (uint32_t)__popcll(__ballot(start));
+            MIRT_STATS(tc1 = clock64());
+            pool_submit<FT>(scene_now(), pool, pool_state, submit, ray, wk.closest, wk.best);
+            walking = walking || submit;
+            // (a workgroup that still iterates after this many iterations has lost a ray: leave instead of hanging)
+            if (!pool_rounds<FT>(scene_now(), pool, pool_state, alive && rounds < (1u << 20), pool_stop, pool_steps, bvh_stack)) break;
+            if (walking && (pool.meta[threadIdx.x] & kMetaDone)) {
+                wk.closest = pool.a[threadIdx.x].w;
+                wk.best = __float_as_int(pool.d[threadIdx.x].w);
+                walking = false;
+            }
+            MIRT_STATS(tc2 = clock64());
+            ready = alive && !walking;
+            t = wk.closest;
+            prim = wk.best;
+        } else if constexpr ((FT & F_BVH) != 0) {
             if (alive && !walking && !closed) {
                 DrawKey key{pixel, sample, bounce, a.seed};
                 wk.closest = MIRT_INF;
@@ -542,6 +582,9 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         MIRT_STATS(const long long tc3 = clock64(); ph0 += tc1 - tc0; ph1 += tc2 - tc1; ph2 += tc3 - tc2);
     }
     MIRT_STATS(wave_totals(clock64() - t_birth, ph0, ph1, ph2, rounds));
+    if constexpr (POOL) {
+        if (threadIdx.x == 0 && rounds >= (1u << 20)) atomicOr(a.scene.fault, (uint32_t)FAULT_POOL_STALL);
+    }
     if ((threadIdx.x & 63u) == 0 && a.segment_counter) {
         atomicAdd(a.segment_counter, (unsigned long long)segments);
         atomicAdd(a.segment_counter + 1, 64ull * rounds);
@@ -702,13 +745,30 @@ static uint32_t stack_bytes(const DevScene& s) {
 
 // `kernel_top` (may be the same as `kernel`): the TOP_NODES form of the kernel, launched instead when at least half of
 // the scene's hierarchy nodes fit into the LDS the resident workgroups leave free.
-template <class Kernel, class KernelTop>
-static hipError_t launch_persistent(Kernel kernel, KernelTop kernel_top, const RenderArgs& a_in, hipStream_t stream) {
+// `kernel_pool` (may be the same as `kernel`): the POOL form, launched when the arguments ask for it (a.pool) and the
+// launch does not tally its walks; it takes kPoolBytes of LDS more than the stacks and leaves the nodes in memory.
+template <class Kernel, class KernelTop, class KernelPool>
+static hipError_t launch_persistent(Kernel kernel, KernelTop kernel_top, KernelPool kernel_pool, const RenderArgs& a_in, hipStream_t stream) {
     int device = 0, cus = 0, per_cu = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
     if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device)) != hipSuccess) return e;
     RenderArgs a = a_in;
+    if ((void*)kernel_pool != (void*)kernel && a.pool && !a.count_cost && (a.scene.features & F_BVH) && a.scene.stack_limit + kBvhStackSlack < 256u) {
+        const size_t lds_bytes = stack_bytes(a.scene) + kPoolBytes;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_pool, kBlock, lds_bytes)) != hipSuccess) return e;
+        if (per_cu > 0) {
+            const uint64_t items = (uint64_t)((a.width + 7u) / 8u) * ((a.height + 7u) / 8u) * 64u * a.n_chunks;
+            if (a.n_chunks == 0 || items >= 0xffffff00ull || (uint64_t)a.n_chunks * a.width * a.height >= 0xffffffffull ||
+                (a.n_chunks > 1 && !a.partial))
+                return hipErrorInvalidValue;
+            a.scene.lds_nodes = 0;
+            const uint32_t want = (uint32_t)((items + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(kernel_pool, dim3(std::min(want, (uint32_t)(cus * per_cu))), dim3(kBlock), lds_bytes, stream, a);
+            if ((e = hipGetLastError()) != hipSuccess || a.n_chunks == 1) return e;
+            return launch_reduce_chunks(a, stream);
+        }
+    }
     if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kBlock, stack_bytes(a.scene))) != hipSuccess) return e;
     // Nodes of the hierarchies kept in LDS behind the stacks: as many as fit without costing a resident workgroup
     // (a.scene.lds_nodes arrives as the number of nodes the scene has).
@@ -760,14 +820,17 @@ struct RenderLauncher {
                 return hipGetLastError();
             }
             const bool lq = lds && !(s.features & F_BVH);  // the LDS-table variants carry no traversal stack
-            if (lq && pinhole) return launch_persistent(render_queue_kernel<F, true, true>, render_queue_kernel<F, true, true>, a, stream);
-            if (lq) return launch_persistent(render_queue_kernel<F, true, false>, render_queue_kernel<F, true, false>, a, stream);
+            if (lq && pinhole) return launch_persistent(render_queue_kernel<F, true, true>, render_queue_kernel<F, true, true>, render_queue_kernel<F, true, true>, a, stream);
+            if (lq) return launch_persistent(render_queue_kernel<F, true, false>, render_queue_kernel<F, true, false>, render_queue_kernel<F, true, false>, a, stream);
             if constexpr ((F & F_BVH) != 0) {
-                if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true, true>, a, stream);
-                return launch_persistent(render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false, true>, a, stream);
+                if (pinhole)
+                    return launch_persistent(render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true, true>,
+                                             render_queue_kernel<F, false, true, false, true>, a, stream);
+                return launch_persistent(render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false, true>,
+                                         render_queue_kernel<F, false, false, false, true>, a, stream);
             }
-            if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true>, a, stream);
-            return launch_persistent(render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false>, a, stream);
+            if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true>, a, stream);
+            return launch_persistent(render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false>, a, stream);
         }
         if (lds && pinhole) hipLaunchKernelGGL((render_fused_kernel<F, true, true>), grid, block, stack_bytes(s), stream, a);
         else if (lds) hipLaunchKernelGGL((render_fused_kernel<F, true, false>), grid, block, stack_bytes(s), stream, a);

@@ -776,7 +776,7 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
     if (!c->accum || p->width != c->width || p->height != c->height)
         return fail(c, MIRT_ERR_STATE, w + ": width/height differ from mirt_frame_begin");
     if ((uint64_t)p->spp_begin + p->spp_count > 0xffffffffull) return fail(c, MIRT_ERR_INVALID, w + ": sample range overflows 32 bits");
-    if ((p->kernel & 0xffu) > MIRT_KERNEL_QUEUE || (p->kernel & ~(0xffu | MIRT_KERNEL_COUNT_WALKS | MIRT_KERNEL_WF_CLASSES))) return fail(c, MIRT_ERR_INVALID, w + ": unknown kernel selector");
+    if ((p->kernel & 0xffu) > MIRT_KERNEL_QUEUE || (p->kernel & ~(0xffu | MIRT_KERNEL_COUNT_WALKS | MIRT_KERNEL_WF_CLASSES | MIRT_KERNEL_POOL))) return fail(c, MIRT_ERR_INVALID, w + ": unknown kernel selector");
     const uint32_t selector = p->kernel & 0xffu;
     HIP_TRY(c, hipSetDevice(c->device));
     RenderArgs a{};
@@ -811,6 +811,11 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
         a.walk_budget = budget_env > 0 ? (uint32_t)budget_env : (heavy_iteration ? 96u : 48u);
         a.walk_min_lanes = lanes_env >= 0 ? (uint32_t)lanes_env : (heavy_iteration ? 6u : 24u);
         a.walk_node_lanes = node_env >= 0 ? (uint32_t)node_env : (heavy_iteration ? 8u : 16u);
+        // the pooled form of the walk (MIRT_KERNEL_POOL; MIRT_POOL=0/1 overrides for A/B runs of whole programs)
+        static const long pool_env = env("MIRT_POOL"), pool_stop_env = env("MIRT_POOL_STOP"), pool_steps_env = env("MIRT_POOL_STEPS");
+        a.pool = pool_env >= 0 ? (pool_env ? 1u : 0u) : ((p->kernel & MIRT_KERNEL_POOL) ? 1u : 0u);
+        a.pool_stop = pool_stop_env > 0 ? (uint32_t)pool_stop_env : 32u;
+        a.pool_steps = pool_steps_env > 0 ? (uint32_t)pool_steps_env : 2u;
     }
     // Long renders are cut into launches of at most kChunk samples per pixel: lanes of a wave
     // then finish within a few percent of each other and no launch runs for seconds.
