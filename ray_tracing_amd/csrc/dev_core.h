@@ -325,22 +325,62 @@ template <uint32_t F>
 MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, float t_min, float t_max, const DrawKey& key,
                          float& t_out);
 
+// closest = t, best = prim in the lanes where  t_min <= t <= closest,  lo0 <= x <= hi0  and  lo1 <= y <= hi1  — the
+// range and extent tests of geo.rs:199-204 in accepting form (a NaN fails every compare) — written with compares that
+// narrow the execution mask one after the other (v_cmpx) and two moves under the narrowed mask. The compiler's code for
+// the same expression is six compares into scalar pairs, five s_and_b64 to join them and two selects, thirteen
+// instructions against ten here; the render kernels are bound by the NUMBER of instructions a wave issues, scalar ones
+// included (profiles/r3/probe_instruction_cost.txt), so the three are worth having. The first instruction saves the
+// execution mask and also separates the compares from whatever packed instruction produced t, x or y.
+// EXT: "s" when the extents and the id are wave-uniform (a scan record in scalar registers), "v" when they differ
+// from lane to lane (a leaf record). TMIN: the same for t_min (the scan of a medium's boundary list starts its second
+// pass at a per-lane t_min, geo.rs:416).
+#ifdef __HIP_DEVICE_COMPILE__
+#define MIRT_RECT_ACCEPT(EXT, TMIN, t, x, y, t_min, lo0, hi0, lo1, hi1, prim, closest, best)                                      \
+    do {                                                                                                                  \
+        unsigned long long mirt_saved_exec;                                                                               \
+        asm volatile(                                                                                                     \
+            "s_mov_b64 %[sv], exec\n"                                                                                     \
+            "v_cmpx_le_f32 %[tm], %[tt]\n"                                                                                \
+            "v_cmpx_ge_f32 %[cl], %[tt]\n"                                                                                \
+            "v_cmpx_le_f32 %[l0], %[xx]\n"                                                                                \
+            "v_cmpx_ge_f32 %[h0], %[xx]\n"                                                                                \
+            "v_cmpx_le_f32 %[l1], %[yy]\n"                                                                                \
+            "v_cmpx_ge_f32 %[h1], %[yy]\n"                                                                                \
+            "v_mov_b32 %[cl], %[tt]\n"                                                                                    \
+            "v_mov_b32 %[bb], %[pp]\n"                                                                                    \
+            "s_mov_b64 exec, %[sv]\n"                                                                                     \
+            : [cl] "+v"(closest), [bb] "+v"(best), [sv] "=&s"(mirt_saved_exec)                                            \
+            : [tt] "v"(t), [xx] "v"(x), [yy] "v"(y), [tm] TMIN(t_min), [l0] EXT(lo0), [h0] EXT(hi0), [l1] EXT(lo1),        \
+              [h1] EXT(hi1), [pp] EXT(prim)                                                                               \
+            : "vcc");                                                                                                     \
+    } while (0)
+#else
+#define MIRT_RECT_ACCEPT(EXT, TMIN, t, x, y, t_min, lo0, hi0, lo1, hi1, prim, closest, best)                                      \
+    do {                                                                                                                  \
+        if (((t) >= (t_min)) & ((t) <= (closest)) & ((x) >= (lo0)) & ((x) <= (hi0)) & ((y) >= (lo1)) & ((y) <= (hi1))) {  \
+            closest = (t);                                                                                                \
+            best = (int)(prim);                                                                                           \
+        }                                                                                                                 \
+    } while (0)
+#endif
+
 // geo.rs:198-204 on one scan record (f = k, lo0, hi0, lo1, hi1), written in accepting form so that a
 // NaN t (direction parallel to the plane) is a miss. XI, YI, ZI = geo.rs:160-166.
-template <uint32_t XI, uint32_t YI, uint32_t ZI>
-MIRT_DEV bool rect_rec_hit(const float* f, const LRay& l, float t_min, float t_max, float& t_out) {
+template <uint32_t XI, uint32_t YI, uint32_t ZI, bool UNIFORM_TMIN>
+MIRT_DEV void rect_rec_hit(const float* f, uint32_t prim, const LRay& l, float t_min, float& closest, int& best) {
     float t = div_nr(f[0] - comp(l.r.o, ZI), comp(l.r.d, ZI), comp(l.rinv, ZI));
     float x = comp(l.r.o, XI) + t * comp(l.r.d, XI);
     float y = comp(l.r.o, YI) + t * comp(l.r.d, YI);
-    t_out = t;
-    return (t >= t_min) & (t <= t_max) & (x >= f[1]) & (x <= f[2]) & (y >= f[3]) & (y <= f[4]);
+    if constexpr (UNIFORM_TMIN) MIRT_RECT_ACCEPT("s", "s", t, x, y, t_min, f[1], f[2], f[3], f[4], prim, closest, best);
+    else MIRT_RECT_ACCEPT("s", "v", t, x, y, t_min, f[1], f[2], f[3], f[4], prim, closest, best);
 }
 
 // Two consecutive rects of one axis (f = k, lo0, hi0, lo1, hi1, each as the pair a, b): the same
 // operations as two rect_rec_hit calls, in the same order and with the same roundings, but the plane
 // distances and hit coordinates of both rects come from packed two-float instructions (8 instead of
 // 16). Rect b is tested against the range rect a has already narrowed, as in the sequential scan.
-template <uint32_t XI, uint32_t YI, uint32_t ZI>
+template <uint32_t XI, uint32_t YI, uint32_t ZI, bool UNIFORM_TMIN>
 MIRT_DEV void rect_pair_hit(const float* f, uint32_t prim_a, uint32_t prim_b, V3 o, V3 d, V3 rinv, float t_min, float& closest, int& best) {
     const float oz = comp(o, ZI), dz = comp(d, ZI), rz = comp(rinv, ZI);
     const float ox = comp(o, XI), dx = comp(d, XI), oy = comp(o, YI), dy = comp(d, YI);
@@ -350,12 +390,13 @@ MIRT_DEV void rect_pair_hit(const float* f, uint32_t prim_a, uint32_t prim_b, V3
     const f32x2 t = __builtin_elementwise_fma(e, (f32x2)rz, q);  // div_nr on both halves
     const f32x2 x = ox + t * dx;
     const f32x2 y = oy + t * dy;
-    const bool ha = (t.x >= t_min) & (t.x <= closest) & (x.x >= f[2]) & (x.x <= f[4]) & (y.x >= f[6]) & (y.x <= f[8]);
-    closest = ha ? t.x : closest;
-    best = ha ? (int)prim_a : best;
-    const bool hb = (t.y >= t_min) & (t.y <= closest) & (x.y >= f[3]) & (x.y <= f[5]) & (y.y >= f[7]) & (y.y <= f[9]);
-    closest = hb ? t.y : closest;
-    best = hb ? (int)prim_b : best;
+    if constexpr (UNIFORM_TMIN) {
+        MIRT_RECT_ACCEPT("s", "s", t.x, x.x, y.x, t_min, f[2], f[4], f[6], f[8], prim_a, closest, best);
+        MIRT_RECT_ACCEPT("s", "s", t.y, x.y, y.y, t_min, f[3], f[5], f[7], f[9], prim_b, closest, best);
+    } else {
+        MIRT_RECT_ACCEPT("s", "v", t.x, x.x, y.x, t_min, f[2], f[4], f[6], f[8], prim_a, closest, best);
+        MIRT_RECT_ACCEPT("s", "v", t.y, x.y, y.y, t_min, f[3], f[5], f[7], f[9], prim_b, closest, best);
+    }
 }
 
 // The two opposite faces of a cuboid on one axis (geo.rs:253-283: planes k_lo and k_hi with the same
@@ -371,12 +412,9 @@ MIRT_DEV void face_pair_hit(float k_lo, float k_hi, float lo0, float hi0, float 
     const f32x2 t = __builtin_elementwise_fma(e, (f32x2)rz, q);
     const f32x2 x = ox + t * dx;
     const f32x2 y = oy + t * dy;
-    const bool ha = (t.x >= t_min) & (t.x <= closest) & (x.x >= lo0) & (x.x <= hi0) & (y.x >= lo1) & (y.x <= hi1);
-    closest = ha ? t.x : closest;
-    best = ha ? (int)prim : best;
-    const bool hb = (t.y >= t_min) & (t.y <= closest) & (x.y >= lo0) & (x.y <= hi0) & (y.y >= lo1) & (y.y <= hi1);
-    closest = hb ? t.y : closest;
-    best = hb ? (int)(prim + 1u) : best;
+    const uint32_t prim_b = prim + 1u;
+    MIRT_RECT_ACCEPT("v", "v", t.x, x.x, y.x, t_min, lo0, hi0, lo1, hi1, prim, closest, best);
+    MIRT_RECT_ACCEPT("v", "v", t.y, x.y, y.y, t_min, lo0, hi0, lo1, hi1, prim_b, closest, best);
 }
 
 // HittableList::hit (ray.rs:123-133) over the scan records [first, first + count) of a list:
@@ -402,12 +440,12 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
         }
         float t = 0.f;
         bool h = false;
-        if ((F & F_RECT) && code == SC_RECT2_XY) rect_pair_hit<0, 1, 2>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
-        else if ((F & F_RECT) && code == SC_RECT2_XZ) rect_pair_hit<0, 2, 1>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
-        else if ((F & F_RECT) && code == SC_RECT2_YZ) rect_pair_hit<1, 2, 0>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
-        else if ((F & F_RECT) && code == SC_RECT_XY) h = rect_rec_hit<0, 1, 2>(rec.f, lr, t_min, closest, t);
-        else if ((F & F_RECT) && code == SC_RECT_XZ) h = rect_rec_hit<0, 2, 1>(rec.f, lr, t_min, closest, t);
-        else if ((F & F_RECT) && code == SC_RECT_YZ) h = rect_rec_hit<1, 2, 0>(rec.f, lr, t_min, closest, t);
+        if ((F & F_RECT) && code == SC_RECT2_XY) rect_pair_hit<0, 1, 2, ALLOW_MEDIUM>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
+        else if ((F & F_RECT) && code == SC_RECT2_XZ) rect_pair_hit<0, 2, 1, ALLOW_MEDIUM>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
+        else if ((F & F_RECT) && code == SC_RECT2_YZ) rect_pair_hit<1, 2, 0, ALLOW_MEDIUM>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
+        else if ((F & F_RECT) && code == SC_RECT_XY) rect_rec_hit<0, 1, 2, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best);
+        else if ((F & F_RECT) && code == SC_RECT_XZ) rect_rec_hit<0, 2, 1, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best);
+        else if ((F & F_RECT) && code == SC_RECT_YZ) rect_rec_hit<1, 2, 0, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best);
         else if ((F & F_SPHERE) && code == SC_SPHERE) h = sphere_hit_c(v3(rec.f), rec.f[3], lr.r, t_min, closest, t);
         else if ((F & F_MOVING) && code == SC_SPHERE_MOVING) {
             const DevPrim q = load_const(s.prims + rec.prim);

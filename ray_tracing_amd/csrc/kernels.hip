@@ -456,6 +456,15 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     }
     while (POOL || __ballot(alive) != 0) {
         ++rounds;
+#ifdef MIRT_PROBE_SALU  // measurement builds only: what 100 more scalar / vector instructions per iteration cost
+        { uint32_t dummy; asm volatile("s_mov_b32 %0, 0\n .rept 100\n s_add_u32 %0, %0, 1\n .endr" : "=s"(dummy) : : "scc"); asm volatile("" : : "s"(dummy)); }
+#endif
+#ifdef MIRT_PROBE_VALU_FAST
+        { uint32_t d0 = threadIdx.x, d1 = rounds, d2 = 3, d3 = 7; asm volatile(".rept 25\n v_add_u32 %0, %0, %1\n v_add_u32 %1, %1, %2\n v_add_u32 %2, %2, %3\n v_add_u32 %3, %3, %0\n .endr" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)); if (d0 + d1 + d2 + d3 == 0xdeadbeefu) ++segments; }
+#endif
+#ifdef MIRT_PROBE_VALU_SLOW
+        { uint32_t d0 = threadIdx.x, d1 = rounds, d2 = 3, d3 = 7; asm volatile(".rept 25\n v_max_u32 %0, %0, %1\n v_max_u32 %1, %1, %2\n v_max_u32 %2, %2, %3\n v_max_u32 %3, %3, %0\n .endr" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)); if (d0 + d1 + d2 + d3 == 0xdeadbeefu) ++segments; }
+#endif
         // ---- trace: scene.world.hit (renderer.rs:201). The lists are scanned in the iteration that starts
         //      the segment; the hierarchies are walked a bounded number of steps per iteration, and a lane
         //      whose walk is not over sits out the rest of the iteration and continues in the next one.
