@@ -676,23 +676,26 @@ MIRT_DEV void walk_push(Walk& w, uint32_t* stack, uint32_t stride, bool on, uint
 // ordered breadth first, so these are the nodes nearest the roots; a lane whose node is among them reads it from LDS
 // and leaves the vector L1 — whose throughput, at 112 bytes per lane and step, bounds the walks of large trees beside
 // instruction issue — to the lanes deeper down.
+template <bool COUNT = false>
 MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w, uint32_t* stack, uint32_t stride, uint32_t* wave_cost,
                         const uint32_t* top) {
     // Byte offset of the entry quad inside an axis' pair of quads: 0 (low planes) where the ray ascends, 16 (high
     // planes) where it descends. Invariant over the walk: the compiler keeps the three values across the node loop.
     // (A reciprocal of -0 was limited to -2^100 by walk_ray: its sign picks the high planes, and the products say the
     // same: the distances to the high planes are the smaller ones.)
-    const uint32_t sx = (__float_as_uint(rinv.x) >> 31) << 4, sy = (__float_as_uint(rinv.y) >> 31) << 4, sz = (__float_as_uint(rinv.z) >> 31) << 4;
+    // (each with the offset of its axis' pair of quads inside the node: only bit operations between the node's offset and
+    // these, so every fetch is base + one 32-bit offset register)
+    const uint32_t sx = (__float_as_uint(rinv.x) >> 31) << 4, sy = ((__float_as_uint(rinv.y) >> 31) << 4) | 32u, sz = ((__float_as_uint(rinv.z) >> 31) << 4) | 64u;
     const char* const nodes = reinterpret_cast<const char*>(s.bvh_nodes);
     const uint32_t at = w.ref << 7;  // byte offset of the node: the upload refuses more than 2^25 nodes
-    const uint32_t ax = at | sx, ay = (at | sy) + 32u, az = (at | sz) + 64u;
+    const uint32_t ax = at | sx, ay = at | sy, az = at | sz;
     float4 px, qx, py, qy, pz, qz;
     uint4 refs;
     if (top && w.ref < s.lds_nodes) {
         const char* const n = reinterpret_cast<const char*>(top) + w.ref * kLdsNodeStride;
         px = *reinterpret_cast<const float4*>(n + sx); qx = *reinterpret_cast<const float4*>(n + (sx ^ 16u));
-        py = *reinterpret_cast<const float4*>(n + 32u + sy); qy = *reinterpret_cast<const float4*>(n + 32u + (sy ^ 16u));
-        pz = *reinterpret_cast<const float4*>(n + 64u + sz); qz = *reinterpret_cast<const float4*>(n + 64u + (sz ^ 16u));
+        py = *reinterpret_cast<const float4*>(n + sy); qy = *reinterpret_cast<const float4*>(n + (sy ^ 16u));
+        pz = *reinterpret_cast<const float4*>(n + sz); qz = *reinterpret_cast<const float4*>(n + (sz ^ 16u));
         refs = *reinterpret_cast<const uint4*>(n + 96u);
     } else {
         px = *reinterpret_cast<const float4*>(nodes + ax); qx = *reinterpret_cast<const float4*>(nodes + (ax ^ 16u));
@@ -700,9 +703,10 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w,
         pz = *reinterpret_cast<const float4*>(nodes + az); qz = *reinterpret_cast<const float4*>(nodes + (az ^ 16u));
         refs = *reinterpret_cast<const uint4*>(nodes + at + 96u);
     }
-    // a counting launch (wave-uniform) tallies the child boxes the node really has: its first two, and the
-    // third and fourth where they exist
-    if (wave_cost) atomicAdd(wave_cost + 3, 2u + (refs.z != kWalkIdle ? 1u : 0u) + (refs.w != kWalkIdle ? 1u : 0u));
+    // a counting launch tallies the child boxes the node really has: its first two, and the third and fourth where
+    // they exist (COUNT is a template parameter: a test of the pointer here is three instructions per step for every
+    // launch — a branch on the execution mask, since the compiler cannot know the pointer is the same in all lanes)
+    if constexpr (COUNT) atomicAdd(wave_cost + 3, 2u + (refs.z != kWalkIdle ? 1u : 0u) + (refs.w != kWalkIdle ? 1u : 0u));
     const f32x2 rx = {rinv.x, rinv.x}, ry = {rinv.y, rinv.y}, rz = {rinv.z, rinv.z};
     const f32x2 cx = {nc.x, nc.x}, cy = {nc.y, nc.y}, cz = {nc.z, nc.z};
     // entry (n) and exit (f) distances of children (0, 1) and (2, 3) on each axis
@@ -729,9 +733,12 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w,
     walk_push(w, stack, stride, lf < MIRT_INF, pf);
     // (the host sizes the stacks by the exact need of every hierarchy it builds; a stack beyond its limit means that
     // promise was broken, and the dropped children are reported instead of silently missed)
-    if (w.sp > s.stack_limit) {
-        w.sp = s.stack_limit;
-        atomicOr(s.fault, (uint32_t)FAULT_STACK_OVERFLOW);
+    // (asked of the whole wave first: a compare and a scalar branch in the step instead of a region of its own)
+    if (__builtin_expect(__ballot(w.sp > s.stack_limit) != 0, 0)) {
+        if (w.sp > s.stack_limit) {
+            w.sp = s.stack_limit;
+            atomicOr(s.fault, (uint32_t)FAULT_STACK_OVERFLOW);
+        }
     }
     if (kn < MIRT_INF) w.ref = rn;
     else walk_pop(w, stack, stride);
@@ -818,7 +825,7 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
 //   node_lanes  fewer lanes than this are still descending through interior nodes: the descent pauses and the
 //               lanes that hold leaves intersect them now rather than after the last straggler.
 // `steps` receives the number of steps taken (statistics builds read it; otherwise it folds away).
-template <uint32_t F>
+template <uint32_t F, bool COUNT = false>
 MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n, uint32_t budget, uint32_t min_lanes,
                         uint32_t node_lanes, uint32_t* stack, uint32_t stride, uint32_t& steps, uint32_t* wave_cost,
                         const uint32_t* top = nullptr) {
@@ -839,7 +846,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
         if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w, lr);
         while (w.ref != kWalkIdle && steps < budget) {
             while (ref_is_node(w.ref) && steps < budget) {
-                walk_node(s, t_min, lr.rinv, lr.nc, w, stack, stride, wave_cost, top);
+                walk_node<COUNT>(s, t_min, lr.rinv, lr.nc, w, stack, stride, wave_cost, top);
                 ++steps;
                 if ((uint32_t)__popcll(__ballot(ref_is_node(w.ref))) < node_lanes) break;
             }
@@ -847,7 +854,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
                 walk_leaf<F>(s, t_min, lr, w, stack, stride, tally);
                 tally += kTallyLeafStep;
                 ++steps;
-                if (wave_cost && (tally & 1023u) >= 64u) flush_tally();
+                if (COUNT && (tally & 1023u) >= 64u) flush_tally();
             }
             // few lanes left walking: they stop here too and go on next iteration, together with the walks
             // the other lanes will have started by then
@@ -855,7 +862,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
         }
         if (w.ref != kWalkIdle || w.next >= n) break;  // out of budget, or every hierarchy walked
     }
-    if (wave_cost) flush_tally();  // wave-uniform: a counting launch
+    if (COUNT) flush_tally();
     return w.ref == kWalkIdle;
 }
 

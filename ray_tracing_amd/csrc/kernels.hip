@@ -292,8 +292,11 @@ __device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* co
 // (walk_node). Launched only where most of the scene's nodes fit (launch_persistent): the second fetch path in the
 // node step costs 2-4 % by itself and pays when few steps need it.
 // POOL: the hierarchy walks of the workgroup's 256 lanes advance together in LDS (dev_pool.h) instead of lane by lane.
-template <uint32_t F, bool LDS_TABLES, bool PINHOLE, bool TOP_NODES = false, bool POOL = false>
+// COUNT: the hierarchy walks tally their node steps and leaf tests (a.count_cost launches; a form of its own so that the
+// timed form carries neither the tallies nor a test for them in its node step).
+template <uint32_t F, bool LDS_TABLES, bool PINHOLE, bool TOP_NODES = false, bool POOL = false, bool COUNT = false>
 __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(RenderArgs a) {
+    static_assert(!COUNT || (!LDS_TABLES && !TOP_NODES && !POOL && (F & F_BVH) != 0), "the counting form is a form of the plain hierarchy variants");
     static_assert(!POOL || (!LDS_TABLES && !TOP_NODES && (F & F_BVH) != 0), "the pooled walk is a form of the hierarchy variants");
     // the LDS-table variants are only launched for scenes without a hierarchy: no traversal code, no stack
     constexpr uint32_t FT = LDS_TABLES ? (F & ~(uint32_t)F_BVH) : F;
@@ -360,7 +363,6 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     __shared__ uint32_t s_walk_cost[(FT & F_BVH) ? (kBlock / 64) * 4 : 1];  // per wave: node steps, leaf spheres, leaf rects, child boxes
     uint32_t* const wave_words = s_walk_cost + ((FT & F_BVH) ? (threadIdx.x >> 6) * 4u : 0u);
     if ((FT & F_BVH) && (threadIdx.x & 63u) == 0u) wave_words[0] = wave_words[1] = wave_words[2] = wave_words[3] = 0u;
-    uint32_t* const wave_cost = a.count_cost ? wave_words : nullptr;  // only a counting launch tallies (walk_some)
     // the hierarchies' nodes nearest the roots, copied behind the stacks (walk_node)
     const uint32_t* top = nullptr;
     if constexpr ((FT & F_BVH) != 0 && TOP_NODES) {
@@ -516,8 +518,8 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
             // the lane thresholds are stated for a full wave: scale them to the lanes this wave still has
             const uint32_t live = (uint32_t)__popcll(__ballot(alive));
             if (alive && !closed)
-                walking = !walk_some<FT>(scene_now(), ray, 0.001f, wk, walk_n, walk_budget, (walk_min_lanes * live) >> 6,
-                                         (walk_node_lanes * live) >> 6, stack, kBlock, wsteps, wave_cost, top);
+                walking = !walk_some<FT, COUNT>(scene_now(), ray, 0.001f, wk, walk_n, walk_budget, (walk_min_lanes * live) >> 6,
+                                                (walk_node_lanes * live) >> 6, stack, kBlock, wsteps, COUNT ? wave_words : nullptr, top);
             MIRT_STATS(tc2 = clock64());
             MIRT_STATS(walk_histogram(alive, wsteps));
             ready = alive && !walking;
@@ -597,8 +599,8 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     if ((threadIdx.x & 63u) == 0 && a.segment_counter) {
         atomicAdd(a.segment_counter, (unsigned long long)segments);
         atomicAdd(a.segment_counter + 1, 64ull * rounds);
-        if constexpr ((FT & F_BVH) != 0) {
-            if (a.count_cost) {
+        if constexpr ((FT & F_BVH) != 0 && COUNT) {
+            {
                 atomicAdd(a.segment_counter + 2, (unsigned long long)wave_words[0]);
                 atomicAdd(a.segment_counter + 3, (unsigned long long)wave_words[1]);
                 atomicAdd(a.segment_counter + 4, (unsigned long long)wave_words[2]);
@@ -756,8 +758,11 @@ static uint32_t stack_bytes(const DevScene& s) {
 // the scene's hierarchy nodes fit into the LDS the resident workgroups leave free.
 // `kernel_pool` (may be the same as `kernel`): the POOL form, launched when the arguments ask for it (a.pool) and the
 // launch does not tally its walks; it takes kPoolBytes of LDS more than the stacks and leaves the nodes in memory.
-template <class Kernel, class KernelTop, class KernelPool>
-static hipError_t launch_persistent(Kernel kernel, KernelTop kernel_top, KernelPool kernel_pool, const RenderArgs& a_in, hipStream_t stream) {
+// `kernel_count` (may be the same as `kernel`): the COUNT form, launched when the arguments ask for the walks' tallies.
+template <class Kernel, class KernelTop, class KernelPool, class KernelCount>
+static hipError_t launch_persistent(Kernel kernel, KernelTop kernel_top, KernelPool kernel_pool, KernelCount kernel_count, const RenderArgs& a_in,
+                                    hipStream_t stream) {
+    if ((void*)kernel_count != (void*)kernel && a_in.count_cost) return launch_persistent(kernel_count, kernel_count, kernel_count, kernel_count, a_in, stream);
     int device = 0, cus = 0, per_cu = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
@@ -829,17 +834,17 @@ struct RenderLauncher {
                 return hipGetLastError();
             }
             const bool lq = lds && !(s.features & F_BVH);  // the LDS-table variants carry no traversal stack
-            if (lq && pinhole) return launch_persistent(render_queue_kernel<F, true, true>, render_queue_kernel<F, true, true>, render_queue_kernel<F, true, true>, a, stream);
-            if (lq) return launch_persistent(render_queue_kernel<F, true, false>, render_queue_kernel<F, true, false>, render_queue_kernel<F, true, false>, a, stream);
+            if (lq && pinhole) return launch_persistent(render_queue_kernel<F, true, true>, render_queue_kernel<F, true, true>, render_queue_kernel<F, true, true>, render_queue_kernel<F, true, true>, a, stream);
+            if (lq) return launch_persistent(render_queue_kernel<F, true, false>, render_queue_kernel<F, true, false>, render_queue_kernel<F, true, false>, render_queue_kernel<F, true, false>, a, stream);
             if constexpr ((F & F_BVH) != 0) {
                 if (pinhole)
                     return launch_persistent(render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true, true>,
-                                             render_queue_kernel<F, false, true, false, true>, a, stream);
+                                             render_queue_kernel<F, false, true, false, true>, render_queue_kernel<F, false, true, false, false, true>, a, stream);
                 return launch_persistent(render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false, true>,
-                                         render_queue_kernel<F, false, false, false, true>, a, stream);
+                                         render_queue_kernel<F, false, false, false, true>, render_queue_kernel<F, false, false, false, false, true>, a, stream);
             }
-            if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true>, a, stream);
-            return launch_persistent(render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false>, a, stream);
+            if (pinhole) return launch_persistent(render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true>, render_queue_kernel<F, false, true>, a, stream);
+            return launch_persistent(render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false>, render_queue_kernel<F, false, false>, a, stream);
         }
         if (lds && pinhole) hipLaunchKernelGGL((render_fused_kernel<F, true, true>), grid, block, stack_bytes(s), stream, a);
         else if (lds) hipLaunchKernelGGL((render_fused_kernel<F, true, false>), grid, block, stack_bytes(s), stream, a);

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(kWfBlock, 5) void wf_walk_kernel(WfArgs a) {
             // (after a short fetch enough lanes are idle already: one step, then the next fetch)
             uint32_t steps;
             const uint32_t min_lanes = exhausted ? 0u : (n_busy > 64u - refill ? 64u - refill + 1u : n_busy + 1u);
-            const bool done = walk_some<F>(a.r.scene, ray, 0.001f, w, n_h, a.r.walk_budget, min_lanes, a.r.walk_node_lanes, stack, kWfBlock, steps, wave_cost);
+            const bool done = a.r.count_cost ? walk_some<F, true>(a.r.scene, ray, 0.001f, w, n_h, a.r.walk_budget, min_lanes, a.r.walk_node_lanes, stack, kWfBlock, steps, wave_cost)
+                                             : walk_some<F, false>(a.r.scene, ray, 0.001f, w, n_h, a.r.walk_budget, min_lanes, a.r.walk_node_lanes, stack, kWfBlock, steps, nullptr);
             if (done) {
                 a.st.q_d[cur][entry].w = w.closest;
                 a.st.q_h[cur][entry].x = (uint32_t)w.best;
