@@ -417,11 +417,76 @@ MIRT_DEV void face_pair_hit(float k_lo, float k_hi, float lo0, float hi0, float 
     MIRT_RECT_ACCEPT("v", "v", t.y, x.y, y.y, t_min, lo0, hi0, lo1, hi1, prim_b, closest, best);
 }
 
+// closest = t, best = prim in the lanes where  t_min <= t <= limit  (the range test of geo.rs:100-104 in accepting
+// form), as two narrowing compares and two moves under the narrowed mask; see MIRT_RECT_ACCEPT.
+#ifdef __HIP_DEVICE_COMPILE__
+#define MIRT_RANGE_ACCEPT(TMIN, PRIM, t, t_min, limit, prim, closest, best)                                                \
+    do {                                                                                                                  \
+        unsigned long long mirt_saved_exec;                                                                               \
+        asm volatile(                                                                                                     \
+            "s_mov_b64 %[sv], exec\n"                                                                                     \
+            "v_cmpx_le_f32 %[tm], %[tt]\n"                                                                                \
+            "v_cmpx_ge_f32 %[lm], %[tt]\n"                                                                                \
+            "v_mov_b32 %[cl], %[tt]\n"                                                                                    \
+            "v_mov_b32 %[bb], %[pp]\n"                                                                                    \
+            "s_mov_b64 exec, %[sv]\n"                                                                                     \
+            : [cl] "+v"(closest), [bb] "+v"(best), [sv] "=&s"(mirt_saved_exec)                                            \
+            : [tt] "v"(t), [lm] "v"(limit), [tm] TMIN(t_min), [pp] PRIM(prim)                                             \
+            : "vcc");                                                                                                     \
+    } while (0)
+#else
+#define MIRT_RANGE_ACCEPT(TMIN, PRIM, t, t_min, limit, prim, closest, best)                                                \
+    do {                                                                                                                  \
+        if (((t) >= (t_min)) & ((t) <= (limit))) {                                                                        \
+            closest = (t);                                                                                                \
+            best = (int)(prim);                                                                                           \
+        }                                                                                                                 \
+    } while (0)
+#endif
+
+// Sphere::hit (geo.rs:89-105) with the result taken at once: closest = root, best = prim where the nearest root in
+// [t_min, closest] exists. The same arithmetic as sphere_hit_c without its branches: a negative discriminant makes the
+// square root, and with it both roots, NaN, and a NaN fails every compare. geo.rs:100-104 tries the smaller root first
+// and the larger one only if the smaller is out of range; here the larger root is taken first and the smaller one —
+// tested against the range as it was, not as the larger root left it — overrides it.
+template <bool UNIFORM>
+MIRT_DEV void sphere_accept(V3 center, float radius, uint32_t prim, const Ray& r, float t_min, float& closest, int& best) {
+    V3 oc = r.o - center;
+    float a = norm_squared(r.d);
+    float half_b = dot(oc, r.d);
+    float c = norm_squared(oc) - radius * radius;
+    float discriminant = half_b * half_b - a * c;
+    float sqrtd = sqrt_nr(discriminant);
+    float ra = fast_rcp(a);
+    const float root0 = div_nr(-half_b - sqrtd, a, ra), root1 = div_nr(-half_b + sqrtd, a, ra);
+    const float limit = closest;
+    if constexpr (UNIFORM) {
+        MIRT_RANGE_ACCEPT("s", "s", root1, t_min, limit, prim, closest, best);
+        MIRT_RANGE_ACCEPT("s", "s", root0, t_min, limit, prim, closest, best);
+    } else {
+        MIRT_RANGE_ACCEPT("v", "v", root1, t_min, limit, prim, closest, best);
+        MIRT_RANGE_ACCEPT("v", "v", root0, t_min, limit, prim, closest, best);
+    }
+}
+
+// One scan record as sixteen dwords in one scalar load (a 64-byte aligned record: s_load_dwordx16).
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+MIRT_DEV DevScanRec load_scan_record(const DevScanRec* p) {
+    const u32x16 v = *(const __attribute__((address_space(4))) u32x16*)p;  // (a C cast, as in load_const: the address space changes)
+    union {
+        DevScanRec rec;
+        u32x16 words;
+    } u;
+    u.words = v;
+    return u.rec;
+}
+
 // HittableList::hit (ray.rs:123-133) over the scan records [first, first + count) of a list:
 // primitives are visited in list order and `t <= closest` accepts, so the later primitive wins a
 // tie. Records are wave-uniform: one 64-byte scalar load each (the other waves of the SIMD cover its
 // latency; holding the next record in registers as well costs more than it hides), and the kind /
-// axis dispatch is a scalar branch.
+// axis dispatch is a scalar branch. Every kind updates closest / best itself and ends the record: a common tail that
+// selects "hit ? t : closest" would run for the rect records too, which are most of a scan.
 template <uint32_t F, bool ALLOW_MEDIUM>
 MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const Ray& r, float t_min, const DrawKey& key,
                         float& closest, int& best) {
@@ -429,7 +494,7 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
     LRay lr = make_lray(r);
     const DevScanRec* p = s.scan + first;
     for (uint32_t j = 0; j < count; ++j) {
-        const DevScanRec rec = load_const(p + j);
+        const DevScanRec rec = load_scan_record(p + j);
         const uint32_t code = rec.code_inst & 0xffu;
         if (F & F_INSTANCE) {
             const uint32_t inst = rec.code_inst >> 8;
@@ -438,23 +503,31 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
                 lr = make_lray(inst ? to_local(load_const(s.instances + inst), r) : r);
             }
         }
-        float t = 0.f;
-        bool h = false;
-        if ((F & F_RECT) && code == SC_RECT2_XY) rect_pair_hit<0, 1, 2, ALLOW_MEDIUM>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
-        else if ((F & F_RECT) && code == SC_RECT2_XZ) rect_pair_hit<0, 2, 1, ALLOW_MEDIUM>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
-        else if ((F & F_RECT) && code == SC_RECT2_YZ) rect_pair_hit<1, 2, 0, ALLOW_MEDIUM>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best);
-        else if ((F & F_RECT) && code == SC_RECT_XY) rect_rec_hit<0, 1, 2, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best);
-        else if ((F & F_RECT) && code == SC_RECT_XZ) rect_rec_hit<0, 2, 1, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best);
-        else if ((F & F_RECT) && code == SC_RECT_YZ) rect_rec_hit<1, 2, 0, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best);
-        else if ((F & F_SPHERE) && code == SC_SPHERE) h = sphere_hit_c(v3(rec.f), rec.f[3], lr.r, t_min, closest, t);
-        else if ((F & F_MOVING) && code == SC_SPHERE_MOVING) {
-            const DevPrim q = load_const(s.prims + rec.prim);
-            h = sphere_hit_c(sphere_center<F>(q, lr.r.time), q.a[3], lr.r, t_min, closest, t);
-        } else if (ALLOW_MEDIUM && (F & F_MEDIUM) && code == SC_MEDIUM) {
-            h = medium_hit<F>(s, load_const(s.prims + rec.prim), r, t_min, closest, key, t);
+        switch (code) {
+            case SC_RECT2_XY: if (F & F_RECT) rect_pair_hit<0, 1, 2, ALLOW_MEDIUM>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best); break;
+            case SC_RECT2_XZ: if (F & F_RECT) rect_pair_hit<0, 2, 1, ALLOW_MEDIUM>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best); break;
+            case SC_RECT2_YZ: if (F & F_RECT) rect_pair_hit<1, 2, 0, ALLOW_MEDIUM>(rec.f, rec.prim, rec.prim2, lr.r.o, lr.r.d, lr.rinv, t_min, closest, best); break;
+            case SC_RECT_XY: if (F & F_RECT) rect_rec_hit<0, 1, 2, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best); break;
+            case SC_RECT_XZ: if (F & F_RECT) rect_rec_hit<0, 2, 1, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best); break;
+            case SC_RECT_YZ: if (F & F_RECT) rect_rec_hit<1, 2, 0, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best); break;
+            case SC_SPHERE: if (F & F_SPHERE) sphere_accept<ALLOW_MEDIUM>(v3(rec.f), rec.f[3], rec.prim, lr.r, t_min, closest, best); break;
+            case SC_SPHERE_MOVING:
+                if (F & F_MOVING) {
+                    const DevPrim q = load_const(s.prims + rec.prim);
+                    sphere_accept<ALLOW_MEDIUM>(sphere_center<F>(q, lr.r.time), q.a[3], rec.prim, lr.r, t_min, closest, best);
+                }
+                break;
+            case SC_MEDIUM:
+                if (ALLOW_MEDIUM && (F & F_MEDIUM)) {
+                    float t = 0.f;
+                    if (medium_hit<F>(s, load_const(s.prims + rec.prim), r, t_min, closest, key, t)) {
+                        closest = t;
+                        best = (int)rec.prim;
+                    }
+                }
+                break;
+            default: break;
         }
-        closest = h ? t : closest;
-        best = h ? (int)rec.prim : best;
     }
 }
 
