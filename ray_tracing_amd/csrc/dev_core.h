@@ -526,7 +526,14 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
                     }
                 }
                 break;
-            default: break;
+            default:
+                // (an empty statement that "redefines" closest / best like every other case does: with all paths through
+                // the switch ending in a definition of their own the register allocator keeps the two in place, where a
+                // path that passes them through unchanged made it copy them in and out of every record)
+#ifdef __HIP_DEVICE_COMPILE__
+                asm volatile("" : "+v"(closest), "+v"(best));
+#endif
+                break;
         }
     }
 }
@@ -1128,20 +1135,27 @@ MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 
 // ---------------------------------------------------------------------------------------------
 // geo.rs:223-233 (rect) and geo.rs:136-143 (sphere). Instances are not applied and FlipFace is
 // transparent, as in geo.rs:324-329 and geo.rs:465-470. `p` is wave-uniform (scalar registers).
+// geo.rs:223-233 for a rect of one axis (XI, YI, ZI = geo.rs:160-166 as compile-time constants: the light is the same for
+// the whole wave, so its axis is a scalar branch and the components need no per-lane selects).
+template <uint32_t XI, uint32_t YI, uint32_t ZI>
+MIRT_DEV float rect_light_pdf(const DevPrim& p, V3 origin, V3 v, V3 vinv) {
+    float t = (p.a[0] - comp(origin, ZI)) * comp(vinv, ZI);
+    float x = fma_(t, comp(v, XI), comp(origin, XI));
+    float y = fma_(t, comp(v, YI), comp(origin, YI));
+    bool h = (t >= 0.001f) & (x >= p.a[1]) & (x <= p.a[2]) & (y >= p.a[3]) & (y <= p.b[0]);
+    float area = fabsf((p.a[2] - p.a[1]) * (p.b[0] - p.a[3]));
+    float dis_squared = t * t * fnorm_squared(v);
+    float cosine = fabsf(comp(v, ZI));
+    return h ? dis_squared * fast_rcp(cosine * area) : 0.f;
+}
 template <uint32_t F>
 MIRT_DEV float light_pdf_one(const DevPrim& p, V3 origin, V3 v, V3 vinv) {
     uint32_t kind = p.meta & PM_KIND_MASK;
     if ((F & F_RECT) && kind == PK_RECT) {
-        uint32_t xi, yi, zi;
-        axis_indexes((p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT, xi, yi, zi);
-        float t = (p.a[0] - comp(origin, zi)) * comp(vinv, zi);
-        float x = fma_(t, comp(v, xi), comp(origin, xi));
-        float y = fma_(t, comp(v, yi), comp(origin, yi));
-        bool h = (t >= 0.001f) & (x >= p.a[1]) & (x <= p.a[2]) & (y >= p.a[3]) & (y <= p.b[0]);
-        float area = fabsf((p.a[2] - p.a[1]) * (p.b[0] - p.a[3]));
-        float dis_squared = t * t * fnorm_squared(v);
-        float cosine = fabsf(comp(v, zi));
-        return h ? dis_squared * fast_rcp(cosine * area) : 0.f;
+        const uint32_t axis = (p.meta & PM_AXIS_MASK) >> PM_AXIS_SHIFT;
+        if (axis == 0u) return rect_light_pdf<0, 1, 2>(p, origin, v, vinv);
+        if (axis == 1u) return rect_light_pdf<0, 2, 1>(p, origin, v, vinv);
+        return rect_light_pdf<1, 2, 0>(p, origin, v, vinv);
     }
     if ((F & F_SPHERE) && kind == PK_SPHERE) {
         // probe ray at time 0 (geo.rs:137); nearest root in [0.001, inf)
@@ -1349,5 +1363,13 @@ MIRT_DEV Ray camera_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t w
 
 // renderer.rs:107 — NaN -> 0, +-inf -> 1.
 MIRT_DEV float sanitize(float c) { return isnan(c) ? 0.f : (isinf(c) ? 1.f : c); }
+// The three channels of a sample at once. Almost every sample is finite: one sum of the magnitudes tells (it is finite
+// only if all three are; a sum that overflows merely sends finite channels through the exact path), and a wave none of
+// whose lanes holds anything else skips the per-channel selects.
+MIRT_DEV V3 sanitize3(V3 e) {
+    const float m = (fabsf(e.x) + fabsf(e.y)) + fabsf(e.z);
+    if (__ballot(!(m < MIRT_INF)) == 0) return e;
+    return v3(sanitize(e.x), sanitize(e.y), sanitize(e.z));
+}
 
 }  // namespace mirt

@@ -118,7 +118,7 @@ __device__ __forceinline__ void shade_segment(const RenderArgs& a, const Tables&
         }
     }
     if (ended) {
-        acc = acc + v3(sanitize(e.x), sanitize(e.y), sanitize(e.z));  // renderer.rs:107-109
+        acc = acc + sanitize3(e);  // renderer.rs:107-109
         ++sample;
         alive = sample < sample_end;
     }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 }
             }
             if (ended) {
-                acc = acc + v3(sanitize(e.x), sanitize(e.y), sanitize(e.z));  // renderer.rs:107-109
+                acc = acc + sanitize3(e);  // renderer.rs:107-109
                 ++sample;
             }
         }
