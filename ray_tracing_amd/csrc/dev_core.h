@@ -401,7 +401,8 @@ MIRT_DEV void rect_pair_hit(const float* f, uint32_t prim_a, uint32_t prim_b, V3
 
 // The two opposite faces of a cuboid on one axis (geo.rs:253-283: planes k_lo and k_hi with the same
 // extents [lo0, hi0] x [lo1, hi1]); ids prim and prim + 1. Same arithmetic as rect_pair_hit.
-template <uint32_t XI, uint32_t YI, uint32_t ZI>
+// UNIFORM: the cuboid is a scan record (corners, id and t_min in scalar registers) rather than a leaf record.
+template <uint32_t XI, uint32_t YI, uint32_t ZI, bool UNIFORM = false>
 MIRT_DEV void face_pair_hit(float k_lo, float k_hi, float lo0, float hi0, float lo1, float hi1, uint32_t prim, V3 o, V3 d, V3 rinv,
                             float t_min, float& closest, int& best) {
     const float oz = comp(o, ZI), dz = comp(d, ZI), rz = comp(rinv, ZI);
@@ -413,8 +414,13 @@ MIRT_DEV void face_pair_hit(float k_lo, float k_hi, float lo0, float hi0, float 
     const f32x2 x = ox + t * dx;
     const f32x2 y = oy + t * dy;
     const uint32_t prim_b = prim + 1u;
-    MIRT_RECT_ACCEPT("v", "v", t.x, x.x, y.x, t_min, lo0, hi0, lo1, hi1, prim, closest, best);
-    MIRT_RECT_ACCEPT("v", "v", t.y, x.y, y.y, t_min, lo0, hi0, lo1, hi1, prim_b, closest, best);
+    if constexpr (UNIFORM) {
+        MIRT_RECT_ACCEPT("s", "s", t.x, x.x, y.x, t_min, lo0, hi0, lo1, hi1, prim, closest, best);
+        MIRT_RECT_ACCEPT("s", "s", t.y, x.y, y.y, t_min, lo0, hi0, lo1, hi1, prim_b, closest, best);
+    } else {
+        MIRT_RECT_ACCEPT("v", "v", t.x, x.x, y.x, t_min, lo0, hi0, lo1, hi1, prim, closest, best);
+        MIRT_RECT_ACCEPT("v", "v", t.y, x.y, y.y, t_min, lo0, hi0, lo1, hi1, prim_b, closest, best);
+    }
 }
 
 // closest = t, best = prim in the lanes where  t_min <= t <= limit  (the range test of geo.rs:100-104 in accepting
@@ -510,6 +516,23 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
             case SC_RECT_XY: if (F & F_RECT) rect_rec_hit<0, 1, 2, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best); break;
             case SC_RECT_XZ: if (F & F_RECT) rect_rec_hit<0, 2, 1, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best); break;
             case SC_RECT_YZ: if (F & F_RECT) rect_rec_hit<1, 2, 0, ALLOW_MEDIUM>(rec.f, rec.prim, lr, t_min, closest, best); break;
+            case SC_CUBOID:
+                // The six rects of a cuboid (geo.rs:245-289) that the upload found as three consecutive rect pairs of one
+                // instance: one record of two corners, ids prim .. prim + 5, its instance in prim2. The frame is set up
+                // here and forgotten again, so the records around it keep theirs (the instance bits of this record repeat
+                // the instance current before it).
+                if ((F & F_RECT) && ALLOW_MEDIUM) {
+                    const uint32_t box_inst = (F & F_INSTANCE) ? rec.prim2 : 0u;
+                    LRay cl;
+                    if (box_inst) cl = make_lray(to_local(load_const(s.instances + box_inst), r));
+                    else if (cur_inst == 0u) cl = lr;
+                    else cl = make_lray(r);
+                    const float lx = rec.f[0], ly = rec.f[1], lz = rec.f[2], hx = rec.f[3], hy = rec.f[4], hz = rec.f[5];
+                    face_pair_hit<0, 1, 2, true>(lz, hz, lx, hx, ly, hy, rec.prim, cl.r.o, cl.r.d, cl.rinv, t_min, closest, best);
+                    face_pair_hit<0, 2, 1, true>(ly, hy, lx, hx, lz, hz, rec.prim + 2u, cl.r.o, cl.r.d, cl.rinv, t_min, closest, best);
+                    face_pair_hit<1, 2, 0, true>(lx, hx, ly, hy, lz, hz, rec.prim + 4u, cl.r.o, cl.r.d, cl.rinv, t_min, closest, best);
+                }
+                break;
             case SC_SPHERE: if (F & F_SPHERE) sphere_accept<ALLOW_MEDIUM>(v3(rec.f), rec.f[3], rec.prim, lr.r, t_min, closest, best); break;
             case SC_SPHERE_MOVING:
                 if (F & F_MOVING) {

@@ -296,7 +296,10 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
         r.prim = i;
         return r;
     };
-    auto make_scan = [&](uint32_t first, uint32_t count, uint32_t* scan_first, uint32_t* scan_count) {
+    // merge_cuboids: three consecutive rect-pair records XY, XZ, YZ of one instance whose planes and extents are the six
+    // faces of one box, in the order geo.rs:253-268 builds them, become one SC_CUBOID record of two corners (world lists
+    // only: a medium's boundary keeps its three records, whose shape medium_hit recognises).
+    auto make_scan = [&](uint32_t first, uint32_t count, uint32_t* scan_first, uint32_t* scan_count, bool merge_cuboids) {
         *scan_first = (uint32_t)scan.size();
         for (uint32_t i = first; i < first + count; ++i) {
             const DevLeafRec one = scan_record(i);
@@ -317,6 +320,42 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
             }
             scan.push_back(r);
         }
+        if (merge_cuboids) {
+            std::vector<DevScanRec> merged;
+            uint32_t prev_inst = 0;
+            for (size_t k = *scan_first; k < scan.size(); ++k) {
+                const DevScanRec& a = scan[k];
+                bool box = false;
+                if (k + 2 < scan.size() && (a.code_inst & 0xffu) == SC_RECT2_XY && (scan[k + 1].code_inst & 0xffu) == SC_RECT2_XZ &&
+                    (scan[k + 2].code_inst & 0xffu) == SC_RECT2_YZ && (a.code_inst >> 8) == (scan[k + 1].code_inst >> 8) &&
+                    (a.code_inst >> 8) == (scan[k + 2].code_inst >> 8) && a.prim2 == a.prim + 1 && scan[k + 1].prim == a.prim + 2 &&
+                    scan[k + 1].prim2 == a.prim + 3 && scan[k + 2].prim == a.prim + 4 && scan[k + 2].prim2 == a.prim + 5) {
+                    const float* xy = a.f; const float* xz = scan[k + 1].f; const float* yz = scan[k + 2].f;
+                    // pair record: f = (k_a, k_b, lo0_a, lo0_b, hi0_a, hi0_b, lo1_a, lo1_b, hi1_a, hi1_b)
+                    const float lx = xy[2], hx = xy[4], ly = xy[6], hy = xy[8], lz = xy[0], hz = xy[1];
+                    auto same = [](const float* f, float k_a, float k_b, float l0, float h0, float l1, float h1) {
+                        return f[0] == k_a && f[1] == k_b && f[2] == l0 && f[3] == l0 && f[4] == h0 && f[5] == h0 && f[6] == l1 && f[7] == l1 &&
+                               f[8] == h1 && f[9] == h1;
+                    };
+                    box = same(xy, lz, hz, lx, hx, ly, hy) && same(xz, ly, hy, lx, hx, lz, hz) && same(yz, lx, hx, ly, hy, lz, hz);
+                    if (box) {
+                        DevScanRec c{};
+                        c.code_inst = SC_CUBOID | (prev_inst << 8);  // (the scan's frame stays what it was: list_scan)
+                        c.prim = a.prim;
+                        c.prim2 = a.code_inst >> 8;  // the box's own instance
+                        c.f[0] = lx; c.f[1] = ly; c.f[2] = lz; c.f[3] = hx; c.f[4] = hy; c.f[5] = hz;
+                        merged.push_back(c);
+                        k += 2;
+                    }
+                }
+                if (!box) {
+                    merged.push_back(a);
+                    prev_inst = a.code_inst >> 8;
+                }
+            }
+            scan.resize(*scan_first);
+            scan.insert(scan.end(), merged.begin(), merged.end());
+        }
         *scan_count = (uint32_t)scan.size() - *scan_first;
     };
     if (d->n_instances >= (1u << 24)) return bad("too many instances");
@@ -324,7 +363,7 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
         const mirt_prim& p = d->prims[i];
         if (p.kind != MIRT_PRIM_MEDIUM) continue;
         uint32_t rf, rc;
-        make_scan(p.boundary_first, p.boundary_count, &rf, &rc);
+        make_scan(p.boundary_first, p.boundary_count, &rf, &rc, false);
         std::memcpy(&prims[i].a[0], &rf, 4);
         std::memcpy(&prims[i].a[1], &rc, 4);
         // boundary shapes whose two crossings come from one evaluation (medium_hit in dev_core.h)
@@ -457,7 +496,7 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
         }
         if (kind == MIRT_ENTRY_LIST) {
             q.kind = EK_LIST;
-            make_scan(w.first_prim, w.prim_count, &q.scan_first, &q.scan_count);
+            make_scan(w.first_prim, w.prim_count, &q.scan_first, &q.scan_count, true);
         } else if (kind == MIRT_ENTRY_BVH) {
             if (w.prim_count == 0) return bad("entry " + std::to_string(e) + ": empty BVH (aabb.rs:98)");
             if (w.prim_count % q.prims_per_object) return bad("entry " + std::to_string(e) + ": prim_count is not a multiple of prims_per_object");
