@@ -253,7 +253,8 @@ def main():
                        "config_id": args.config, "samples_per_step": samples_per_step,
                        "parallelism": f"spp-range x{world}" + (" + RCCL reduce" if world > 1 else ""), "rccl_ranks": ctx.comm_ranks()},
             # compute-bound on the vector ALUs (a path tracer has no matrix products: no MFMA), not HBM-bound
-            "roofline": {"bound": "valu", "bound_note": "f32 vector-ALU issue bound; peak = packed f32 FMA rate of the vector ALUs",
+            "roofline": {"bound": "valu", "bound_note": "bound by the instructions a wave issues (vector and scalar alike: 100 more of either per loop iteration cost the same, "
+                                                      "profiles/r3/probe_instruction_cost.txt); peak = packed f32 FMA rate of the vector ALUs",
                          "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "frac_of_unpacked_fma_rate": achieved / UNPACKED_FP32_TFLOPS,
@@ -261,6 +262,7 @@ def main():
                          # from the committed profile of this same command (rocprofv3 --pmc passes, code object notes)
                          "lanes_per_valu": prof.get("lanes_per_valu"), "valu_issue_clk": prof.get("valu_issue_clk"),
                          "vgpr": prof.get("vgpr"), "scratch_bytes": prof.get("scratch_bytes"),
+                         "valu_per_launch": prof.get("valu_per_launch"), "salu_per_launch": prof.get("salu_per_launch"),
                          "kernel": "render_queue_kernel" if st.get("kernel_used") == rt.KERNEL_QUEUE else "render_fused_kernel",
                          "avg_launch_ms": kernel_ms / max(launches, 1),
                          "segments_per_sample": tot["segments"] / (W * H * count * args.steps),
