@@ -734,6 +734,29 @@ MIRT_DEV void walk_begin(const DevScene& s, const Ray& r, Walk& w, LRay& lr) {
     w.sp = 0;
 }
 
+// The hierarchies a ray starts next, without those whose world box it misses (DevScene::bvh_bounds; the slab test of
+// aabb.rs:43-60 against [t_min, closest] on a padded box with the widened far bound of walk_node, so it errs on the
+// side of walking). Most rays of `final` miss its cluster of a thousand spheres: they no longer change frames and
+// fetch its root to find that out, and — the lanes of a wave reach their second hierarchy at different times — no
+// longer cost the wave a node step each time one of them does.
+MIRT_DEV void walk_skip_missed(const DevScene& s, const Ray& r, float t_min, Walk& w, uint32_t n) {
+    constexpr float kRinvMax = 1.2676506e30f;
+    const V3 rinv = v3(__builtin_amdgcn_fmed3f(fast_rcp(r.d.x), -kRinvMax, kRinvMax), __builtin_amdgcn_fmed3f(fast_rcp(r.d.y), -kRinvMax, kRinvMax),
+                       __builtin_amdgcn_fmed3f(fast_rcp(r.d.z), -kRinvMax, kRinvMax));
+    while (w.next < n) {
+        const float4 lo = *reinterpret_cast<const float4*>(s.bvh_bounds + 8u * w.next);
+        if (lo.w == 0.f) break;
+        const float4 hi = *reinterpret_cast<const float4*>(s.bvh_bounds + 8u * w.next + 4u);
+        const float ax = (lo.x - r.o.x) * rinv.x, bx = (hi.x - r.o.x) * rinv.x;
+        const float ay = (lo.y - r.o.y) * rinv.y, by = (hi.y - r.o.y) * rinv.y;
+        const float az = (lo.z - r.o.z) * rinv.z, bz = (hi.z - r.o.z) * rinv.z;
+        const float tn = fmaxf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), t_min);
+        const float tf = fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), fminf(w.closest, 1e38f));
+        if (tn <= tf * 1.000002f) break;
+        ++w.next;
+    }
+}
+
 // Next reference from the lane's stack; idle when the hierarchy is exhausted.
 MIRT_DEV void walk_pop(Walk& w, const uint32_t* stack, uint32_t stride) {
     w.ref = kWalkIdle;
@@ -905,7 +928,9 @@ MIRT_DEV void walk_run(const DevScene& s, const Ray& r, float t_min, Walk& w, ui
     w.ref = kWalkIdle;
     LRay lr;
     uint32_t tally = 0;  // not reported by the callers of whole walks
-    while (w.next < n) {
+    for (;;) {
+        if (s.bvh_bounds) walk_skip_missed(s, r, t_min, w, n);
+        if (w.next >= n) break;
         walk_begin<F>(s, r, w, lr);
         // Two nested loops rather than one step of either kind per iteration: the lanes of a wave
         // descend through interior nodes until each of them holds a leaf (or is done), then all
@@ -946,6 +971,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
     LRay lr = make_lray(r);
     if (w.ref != kWalkIdle) lr = walk_ray<F>(s, r, w.next - 1u);  // resuming inside hierarchy w.next - 1
     for (;;) {
+        if (s.bvh_bounds && w.ref == kWalkIdle) walk_skip_missed(s, r, t_min, w, n);
         if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w, lr);
         while (w.ref != kWalkIdle && steps < budget) {
             while (ref_is_node(w.ref) && steps < budget) {

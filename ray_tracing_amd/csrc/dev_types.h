@@ -178,6 +178,11 @@ struct DevScene {
     const DevBvhNode4* bvh_nodes;
     const DevLeafRec* bvh_leaves;  // leaf primitive records in tree order
     const uint32_t* bvh_entries;   // indices into entries of the EK_BVH ones, in world order
+    // World-space boxes of the hierarchies that are small against the scene (two float4 per hierarchy, bvh_entries
+    // order: low corner with a flag in .w — 1 = test this box before starting the hierarchy — and high corner), padded;
+    // nullptr when no hierarchy is flagged. A ray that misses the box cannot hit a member, so its walk skips the
+    // hierarchy without the change of frame and the root step (walk_skip_missed).
+    const float* bvh_bounds;
     uint32_t n_bvh_entries;
     uint32_t n_prims, n_entries, n_lights, n_media;
     uint32_t n_instances, n_textures;

@@ -466,6 +466,8 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     std::vector<DevEntry> entries(d->n_world);
     std::vector<DevBvhNode4> nodes;   // four-wide nodes of all hierarchies
     uint32_t stack_need = 1;
+    struct EntryBox { float lo[3], hi[3]; };
+    std::vector<EntryBox> entry_boxes;    // world boxes of the hierarchies, in world order
     std::vector<uint32_t> slots;          // first primitive of every leaf record, in tree order
     std::vector<uint8_t> slot_is_cuboid;  // the record stands for the six rects of a cuboid
     int deepest_leaf = 0;
@@ -516,6 +518,29 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
                     prim_bounds(p, d->instances, lo, hi);
                     for (int a = 0; a < 3; ++a) { o.lo[a] = std::min(o.lo[a], lo[a]); o.hi[a] = std::max(o.hi[a], hi[a]); }
                 }
+            }
+            {
+                // the hierarchy's box in the world: the eight corners of its members' union through the entry's
+                // transform (geo.rs:349-362 does the same for RotationY's own box), padded
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (const BuildObject& o : objs)
+                    for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], o.lo[a]); hi[a] = std::max(hi[a], o.hi[a]); }
+                EntryBox box;
+                for (int a = 0; a < 3; ++a) { box.lo[a] = INFINITY; box.hi[a] = -INFINITY; }
+                for (int corner = 0; corner < 8; ++corner) {
+                    float p[3] = {(corner & 1) ? hi[0] : lo[0], (corner & 2) ? hi[1] : lo[1], (corner & 4) ? hi[2] : lo[2]};
+                    if (w.instance) {
+                        const mirt_instance& in = d->instances[w.instance];
+                        const float x = in.cos_theta * p[0] + in.sin_theta * p[2], z = -in.sin_theta * p[0] + in.cos_theta * p[2];
+                        p[0] = x + in.offset[0]; p[1] = p[1] + in.offset[1]; p[2] = z + in.offset[2];
+                    }
+                    for (int a = 0; a < 3; ++a) { box.lo[a] = std::min(box.lo[a], p[a]); box.hi[a] = std::max(box.hi[a], p[a]); }
+                }
+                for (int a = 0; a < 3; ++a) {
+                    const float pad = 1e-4f * std::max(std::max(std::fabs(box.lo[a]), std::fabs(box.hi[a])), box.hi[a] - box.lo[a]) + 1e-4f;
+                    box.lo[a] -= pad; box.hi[a] += pad;
+                }
+                entry_boxes.push_back(box);
             }
             // Objects that are cuboids (six rects in the order and with the extents of geo.rs:253-283) become
             // one leaf record each; other multi-primitive objects keep one record per primitive.
@@ -624,6 +649,30 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
         if (entries[e].kind == EK_BVH) bvh_entries.push_back(e);
     if ((rc = upload(c, bvh_entries, &s.bvh_entries))) return rc;
     s.n_bvh_entries = (uint32_t)bvh_entries.size();
+    {
+        // Hierarchies whose world box is small against the union of all of them (under an eighth of its volume, all
+        // boxes finite) are tested against their box before a walk starts them (walk_skip_missed).
+        std::vector<float> bounds(entry_boxes.size() * 8, 0.f);
+        float ulo[3] = {INFINITY, INFINITY, INFINITY}, uhi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        bool finite = true;
+        for (const EntryBox& b : entry_boxes)
+            for (int a = 0; a < 3; ++a) {
+                ulo[a] = std::min(ulo[a], b.lo[a]); uhi[a] = std::max(uhi[a], b.hi[a]);
+                finite = finite && std::isfinite(b.lo[a]) && std::isfinite(b.hi[a]);
+            }
+        bool any = false;
+        const double uvol = entry_boxes.empty() ? 0.0 : (double)(uhi[0] - ulo[0]) * (uhi[1] - ulo[1]) * (uhi[2] - ulo[2]);
+        for (size_t k = 0; k < entry_boxes.size(); ++k) {
+            const EntryBox& b = entry_boxes[k];
+            const double vol = (double)(b.hi[0] - b.lo[0]) * (b.hi[1] - b.lo[1]) * (b.hi[2] - b.lo[2]);
+            const bool flag = finite && entry_boxes.size() >= 2 && vol * 8.0 < uvol;
+            for (int a = 0; a < 3; ++a) { bounds[8 * k + a] = b.lo[a]; bounds[8 * k + 4 + a] = b.hi[a]; }
+            bounds[8 * k + 3] = flag ? 1.f : 0.f;
+            any = any || flag;
+        }
+        s.bvh_bounds = nullptr;
+        if (any && (rc = upload(c, bounds, &s.bvh_bounds))) return rc;
+    }
     s.n_prims = d->n_prims;
     s.n_entries = d->n_world;
     s.n_lights = d->n_lights;
