@@ -892,12 +892,13 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
         // (24, 16); 1 M spheres at 4K 500 / 1 007; `final` 1 430 with whole walks, 1 285 with (24, 16), 1 610
         // with (8, 8). Where an iteration carries long list scans, media or procedural / image textures
         // (`final`), every extra iteration costs more, so walks are cut less: with the four-wide hierarchy `final`
-        // at 256 samples per pixel gives 1 849 with (budget 48; 8, 8) and 1 913 with (96; 6, 8).
+        // at 256 samples per pixel gives 1 849 with (budget 48; 8, 8) and 1 913 with (96; 6, 8); with the world-box test
+        // before a small hierarchy is started (walk_skip_missed) 2 364 with (96; 6, 8) and 2 397 with (96; 8, 8).
         auto env = [](const char* name) { const char* e = std::getenv(name); return e ? std::atol(e) : -1l; };
         static const long budget_env = env("MIRT_WALK_BUDGET"), lanes_env = env("MIRT_WALK_LANES"), node_env = env("MIRT_NODE_LANES");
         const bool heavy_iteration = (c->scene.features & (F_MEDIUM | F_TEX_NOISE | F_TEX_IMAGE)) != 0 || c->n_scan_records > 8u;
         a.walk_budget = budget_env > 0 ? (uint32_t)budget_env : (heavy_iteration ? 96u : 48u);
-        a.walk_min_lanes = lanes_env >= 0 ? (uint32_t)lanes_env : (heavy_iteration ? 6u : 24u);
+        a.walk_min_lanes = lanes_env >= 0 ? (uint32_t)lanes_env : (heavy_iteration ? 8u : 24u);
         a.walk_node_lanes = node_env >= 0 ? (uint32_t)node_env : (heavy_iteration ? 8u : 16u);
         // the pooled form of the walk (MIRT_KERNEL_POOL; MIRT_POOL=0/1 overrides for A/B runs of whole programs)
         static const long pool_env = env("MIRT_POOL"), pool_stop_env = env("MIRT_POOL_STOP"), pool_steps_env = env("MIRT_POOL_STEPS");

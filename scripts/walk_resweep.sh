@@ -3,8 +3,8 @@
 out=gpurun_out/walk_resweep.txt
 : > $out
 run() { echo "# budget=$1 lanes=$2 node_lanes=$3" >> $out; MIRT_WALK_BUDGET=$1 MIRT_WALK_LANES=$2 MIRT_NODE_LANES=$3 timeout -k 10 120 python scripts/ab.py --reps 2 $4 >> $out 2>&1; }
-for b in 64 96 128; do for l in 4 6 8 12; do for n in 6 8 12; do run $b $l $n final256; done; done; done
-for b in 32 48 64; do for l in 16 24 32; do for n in 12 16 24; do run $b $l $n random; run $b $l $n million; done; done; done
+for b in ${BUDGETS:-64 96 128}; do for l in ${LANES:-4 6 8 12}; do for n in ${NODES:-6 8 12}; do run $b $l $n final256; done; done; done
+[ -n "$FINAL_ONLY" ] || for b in 32 48 64; do for l in 16 24 32; do for n in 12 16 24; do run $b $l $n random; run $b $l $n million; done; done; done
 python3 - <<'PY'
 import re
 best={}
