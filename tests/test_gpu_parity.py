@@ -700,3 +700,36 @@ def test_empty_world_and_zero_samples(rt):
     acc = ctx.read_accum()
     assert (acc[..., :3] == 0).all() and (acc[..., 3] == 4).all()
     assert C.sizeof(d) > 0
+
+
+def test_world_box_of_a_small_hierarchy_loses_no_hit(rt, oracle, earth):
+    """`final` keeps its thousand small spheres in a hierarchy of their own under a rotation and a translation
+    (scene.rs:259-268); the device tests a ray against that hierarchy's padded world box before it changes frames and
+    fetches the root, and skips the hierarchy when the ray misses the box. Rays aimed at points on and just around
+    the box — the cluster occupies x in about [-112, 116], y in [258, 447], z in [345, 576] — must name the same
+    primitive as the oracle's scan of every member (aabb.rs:112-126 has no such test)."""
+    orc, ctx, _ = make(rt, oracle, earth, "final")
+    rng = np.random.default_rng(11)
+    n = 30000
+    lo, hi = np.array([-142.0, 228.0, 315.0]), np.array([146.0, 477.0, 606.0])
+    target = lo + rng.random((n, 3)) * (hi - lo)
+    # a third of the targets snapped onto a face of the (approximate) box, where a ray grazes it
+    face = rng.integers(0, 3, n)
+    snap = rng.random(n) < 0.33
+    side = rng.random(n) < 0.5
+    box_lo, box_hi = np.array([-112.0, 258.0, 345.0]), np.array([116.0, 447.0, 576.0])
+    for a in range(3):
+        m = snap & (face == a)
+        target[m, a] = np.where(side[m], box_lo[a], box_hi[a])
+    # (origins above the ground boxes: a ray that starts between them meets the coinciding faces of two neighbours at
+    # one t, a tie that a hierarchy of another shape than the reference's resolves differently)
+    origin = np.array([278.0, 350.0, -300.0]) + (rng.random((n, 3)) - 0.5) * np.array([1200.0, 400.0, 600.0])
+    d = target - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays = np.concatenate([origin, d, rng.random((n, 1))], axis=1).astype(np.float32)
+    oi, ot = orc.first_hit(rays)
+    gi, gt = ctx.first_hit(rays)
+    cluster = (oi >= 0) & (gi != oi)
+    assert not cluster.any(), (int(cluster.sum()), rays[cluster][:3], oi[cluster][:3], gi[cluster][:3])
+    hit = oi >= 0
+    np.testing.assert_allclose(gt[hit], ot[hit], rtol=1e-5)
