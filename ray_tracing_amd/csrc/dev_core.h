@@ -217,6 +217,34 @@ MIRT_DEV V3 rand_in_unit_sphere(Rng& g) {
         if (fnorm_squared(p) < 1.f) return p;
     }
 }
+MIRT_DEV float unit_range(uint32_t w) { return fma_(2.f, unit_f32(w), -1.f); }  // range(-1, 1) of the draw that took word w
+MIRT_DEV bool sphere_trial(uint32_t wx, uint32_t wy, uint32_t wz, V3& p) {
+    p = v3(unit_range(wx), unit_range(wy), unit_range(wz));
+    return fnorm_squared(p) < 1.f;
+}
+// rand_in_unit_sphere for a stream whose next draw is word 0 of a block, which is where the scatter stream of a bounce
+// stands when a metal or an isotropic material takes its only draws from it. Four trials take twelve words, three whole
+// blocks, so the word of every draw is fixed when the code is compiled: the same draws in the same order as the loop
+// above, without the bookkeeping of a position (some fourteen scalar instructions a draw) and without a block generated
+// for a wave whose lanes are all done. `g` is left as it was: the caller draws nothing from it afterwards.
+MIRT_DEV V3 rand_in_unit_sphere_last(const Rng& g) {
+    uint32_t blk = g.pos >> 2;
+    uint32_t a0 = g.w0, a1 = g.w1, a2 = g.w2, a3 = g.w3;
+    bool have = g.have == blk;
+    for (;;) {
+        V3 p;
+        if (!have) philox4x32_10(g.k0, g.k1, blk, g.c1, g.c2, g.c3, a0, a1, a2, a3);
+        have = false;
+        if (sphere_trial(a0, a1, a2, p)) return p;
+        uint32_t b0, b1, b2, b3;
+        philox4x32_10(g.k0, g.k1, blk + 1, g.c1, g.c2, g.c3, b0, b1, b2, b3);
+        if (sphere_trial(a3, b0, b1, p)) return p;
+        philox4x32_10(g.k0, g.k1, blk + 2, g.c1, g.c2, g.c3, a0, a1, a2, a3);
+        if (sphere_trial(b2, b3, a0, p)) return p;
+        if (sphere_trial(a1, a2, a3, p)) return p;
+        blk += 3;
+    }
+}
 // rand_gen.rs:70-78 — two draws per trial.
 MIRT_DEV V3 rand_in_unit_disk(Rng& g) {
     for (;;) {
@@ -1308,7 +1336,7 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, co
     if ((F & F_MAT_METAL) && mk == MK_METAL) {
         // material.rs:86-100
         V3 reflected = fmadd(ray.d, -2.f * fdot(h.n, ray.d), h.n);
-        V3 sd = fmadd(reflected, m.param, rand_in_unit_sphere(g));
+        V3 sd = fmadd(reflected, m.param, rand_in_unit_sphere_last(g));  // the bounce's first and only draws
         if (!(fdot(h.n, sd) > 0.f)) return false;
         ray.o = h.p;
         ray.d = fnormalize(sd);
@@ -1338,7 +1366,7 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, co
     }
     if ((F & F_MAT_ISOTROPIC) && mk == MK_ISOTROPIC) {
         // material.rs:194-199
-        V3 dir = fnormalize(rand_in_unit_sphere(g));
+        V3 dir = fnormalize(rand_in_unit_sphere_last(g));  // the bounce's first and only draws
         V3 att = shade_color<F>(s, m, h);
         ray.o = h.p;
         ray.d = dir;
@@ -1402,11 +1430,38 @@ MIRT_DEV Ray camera_ray(const DevCamera& cam, uint32_t x, uint32_t y, uint32_t w
         r.time = cam.time0;
         return r;
     }
-    V3 rd = cam.lens_radius * rand_in_unit_disk(g);
+    V3 disk;
+    float shutter;
+    if (jitter) {
+        // The stream stands at draw 2 of block 0. Block 1 serves every lane (the second and third trial of the disk,
+        // or the shutter draw of a lane whose first trial held), so it is generated once, for all of them, and the
+        // word of each draw is fixed when the code is compiled: trial 1 = words 2, 3 of block 0, trial 2 = words 0, 1
+        // and trial 3 = words 2, 3 of block 1, the shutter draw = the word after the trial that held. A lane that is
+        // past its second trial (one in 23) goes on in the loop that keeps a position.
+        uint32_t b0, b1, b2, b3;
+        philox4x32_10(g.k0, g.k1, 1u, g.c1, g.c2, g.c3, b0, b1, b2, b3);
+        const float x1 = unit_range(g.w2), y1 = unit_range(g.w3);
+        const float x2 = unit_range(b0), y2 = unit_range(b1);
+        const bool in1 = !(fma_(y1, y1, x1 * x1) >= 1.f);
+        const bool in2 = !(fma_(y2, y2, x2 * x2) >= 1.f);
+        disk = v3(in1 ? x1 : x2, in1 ? y1 : y2, 0.f);
+        shutter = unit_f32(in1 ? b0 : b2);
+        if (!(in1 || in2)) {
+            g.pos = 6;
+            g.have = 1;
+            g.w0 = b0; g.w1 = b1; g.w2 = b2; g.w3 = b3;
+            disk = rand_in_unit_disk(g);
+            shutter = g.next();
+        }
+    } else {
+        disk = rand_in_unit_disk(g);
+        shutter = g.next();
+    }
+    V3 rd = cam.lens_radius * disk;
     V3 offset = fmadd(v3(cam.u) * rd.x, rd.y, v3(cam.v));
     r.o = v3(cam.origin) + offset;
     r.d = fnormalize(target - offset);
-    r.time = g.range(cam.time0, cam.time1);
+    r.time = fma_(cam.time1 - cam.time0, shutter, cam.time0);  // rand_gen.rs:20-23
     return r;
 }
 
