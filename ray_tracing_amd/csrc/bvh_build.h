@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <thread>
 #include <vector>
 #include "dev_types.h"
@@ -150,17 +151,25 @@ class BvhBuilder {
         return r;
     }
 
-    // 16-bin SAH over centroids; returns the partition point or `begin` if no split helps.
+    // Binned SAH over centroids; returns the partition point or `begin` if no split helps. 16 bins, and 128 for a range
+    // of 4096 objects or more: near the root a bin of sixteen holds tens of thousands of objects and the planes fall on
+    // the same few places at every level (1 M spheres: 16.0 -> 13.7 node steps per segment, +13 % samples/s; smaller
+    // scenes measured the same or 1 % slower with more bins, and no better with every partition tried).
+    // MIRT_BVH_BINS, MIRT_BVH_BINS_LARGE (0 = as small ranges) and MIRT_BVH_LARGE_FROM override the three numbers.
     size_t sah_split(std::vector<BuildObject>& objs, size_t begin, size_t end, const float* clo, const float* chi) {
-        constexpr int B = 16;
+        constexpr int BMAX = 256;
+        static const int B_small = [] { const char* v = std::getenv("MIRT_BVH_BINS"); int b = v ? std::atoi(v) : 16; return std::min(std::max(b, 2), 256); }();
+        static const int B_large = [] { const char* v = std::getenv("MIRT_BVH_BINS_LARGE"); int b = v ? std::atoi(v) : 128; return std::min(std::max(b, 0), 256); }();
+        static const size_t large_from = [] { const char* v = std::getenv("MIRT_BVH_LARGE_FROM"); return (size_t)(v ? std::atol(v) : 4096); }();
+        const int B = (B_large && end - begin >= large_from) ? B_large : B_small;
         float best_cost = INFINITY;
         int best_axis = -1, best_bin = -1;
         for (int ax = 0; ax < 3; ++ax) {
             float ext = chi[ax] - clo[ax];
             if (!(ext > 0.f)) continue;
             float scale = (float)B / ext;
-            struct Bin { float lo[3], hi[3]; uint32_t n; } bins[B];
-            for (auto& b : bins) { for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; } b.n = 0; }
+            struct Bin { float lo[3], hi[3]; uint32_t n; } bins[BMAX];
+            for (int q = 0; q < B; ++q) { Bin& b = bins[q]; for (int a = 0; a < 3; ++a) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; } b.n = 0; }
             for (size_t i = begin; i < end; ++i) {
                 float c = 0.5f * (objs[i].lo[ax] + objs[i].hi[ax]);
                 int bi = std::min(B - 1, std::max(0, (int)((c - clo[ax]) * scale)));
@@ -168,8 +177,8 @@ class BvhBuilder {
                 ++b.n;
                 for (int a = 0; a < 3; ++a) { b.lo[a] = std::min(b.lo[a], objs[i].lo[a]); b.hi[a] = std::max(b.hi[a], objs[i].hi[a]); }
             }
-            float la[B], ra[B];
-            uint32_t ln[B], rn[B];
+            float la[BMAX], ra[BMAX];
+            uint32_t ln[BMAX], rn[BMAX];
             float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
             uint32_t cnt = 0;
             for (int i = 0; i < B; ++i) {
@@ -205,11 +214,15 @@ class BvhBuilder {
     }
 };
 
-// Collapses the binary tree rooted at nodes2[root2] into four-wide nodes appended to nodes4: every node takes the
-// children of its interior children in their place (2 to 4 children, in the binary tree's order). Returns the new
+// Collapses the binary tree rooted at nodes2[root2] into four-wide nodes appended to nodes4 (2 to 4 children each, in
+// the binary tree's order). `by_area`: a node starts from the two children of its binary node and, while it has
+// fewer than four, replaces the interior child with the largest surface area by that child's two children — the boxes
+// a ray is most likely to enter are opened in the node itself (1 M spheres +2.4 %, `random` +0.8 % against the other
+// rule: every interior child replaced once, two binary levels per node). Returns the new
 // root's index; *stack_need receives the most references a walk of the new tree can have pushed at once — a step
 // pushes every hit child but the one it enters, so a node with k children adds k - 1 to the deepest need below it.
-inline uint32_t collapse_to_four(const std::vector<DevBvhNode>& nodes2, uint32_t root2, std::vector<DevBvhNode4>& nodes4, uint32_t* stack_need) {
+inline uint32_t collapse_to_four(const std::vector<DevBvhNode>& nodes2, uint32_t root2, std::vector<DevBvhNode4>& nodes4, uint32_t* stack_need,
+                                 bool by_area) {
     struct Child {
         float lo[3], hi[3];
         uint32_t ref;
@@ -233,13 +246,43 @@ inline uint32_t collapse_to_four(const std::vector<DevBvhNode>& nodes2, uint32_t
         Child two[2], kids[4];
         int k = 0;
         children_of(it.n2, two);
-        for (int c = 0; c < 2; ++c) {
-            if (two[c].ref == 0xffffffffu) continue;           // the missing second child of a single-leaf tree
-            if (two[c].ref & 0x80000000u) { kids[k++] = two[c]; continue; }
-            Child grand[2];
-            children_of(two[c].ref, grand);
-            for (int g = 0; g < 2; ++g)
-                if (grand[g].ref != 0xffffffffu) kids[k++] = grand[g];
+        for (int c = 0; c < 2; ++c)
+            if (two[c].ref != 0xffffffffu) kids[k++] = two[c];  // (a single-leaf tree has no second child)
+        if (by_area) {
+            // the interior child with the largest box gives way to its two children, until there are four (of equal
+            // boxes the one fewer binary levels down: identical objects give the balanced node of the other rule)
+            int level[4] = {0, 0, 0, 0};
+            while (k < 4) {
+                int widest = -1;
+                float widest_area = -1.f;
+                for (int c = 0; c < k; ++c) {
+                    if (kids[c].ref & 0x80000000u) continue;
+                    const float dx = kids[c].hi[0] - kids[c].lo[0], dy = kids[c].hi[1] - kids[c].lo[1], dz = kids[c].hi[2] - kids[c].lo[2];
+                    const float area = dx * dy + dy * dz + dz * dx;
+                    if (area > widest_area || (area == widest_area && level[c] < level[widest])) { widest_area = area; widest = c; }
+                }
+                if (widest < 0) break;
+                Child grand[2];
+                children_of(kids[widest].ref, grand);
+                for (int c = k; c > widest + 1; --c) { kids[c] = kids[c - 1]; level[c] = level[c - 1]; }
+                kids[widest] = grand[0];
+                kids[widest + 1] = grand[1];
+                level[widest] = level[widest + 1] = level[widest] + 1;
+                ++k;
+            }
+        } else {
+            // two levels of the binary tree per node
+            Child four[4];
+            int n = 0;
+            for (int c = 0; c < k; ++c) {
+                if (kids[c].ref & 0x80000000u) { four[n++] = kids[c]; continue; }
+                Child grand[2];
+                children_of(kids[c].ref, grand);
+                for (int g = 0; g < 2; ++g)
+                    if (grand[g].ref != 0xffffffffu) four[n++] = grand[g];
+            }
+            k = n;
+            for (int c = 0; c < k; ++c) kids[c] = four[c];
         }
         DevBvhNode4 nd{};
         for (int i = 0; i < 4; ++i) {

@@ -563,7 +563,8 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
             BvhBuilder builder(binary, slots, kBvhStackDepth, records_per_object, std::isfinite(reach) ? reach * 4.76837158e-7f : 0.f);
             const uint32_t root2 = builder.build(objs);
             uint32_t need = 0;
-            q.bvh_root = collapse_to_four(binary, root2, nodes, &need);
+            static const bool by_area = [] { const char* v = std::getenv("MIRT_BVH_BY_AREA"); return v ? std::atoi(v) != 0 : true; }();
+            q.bvh_root = collapse_to_four(binary, root2, nodes, &need, by_area);
             deepest_leaf = std::max(deepest_leaf, builder.deepest_leaf());
             stack_need = std::max(stack_need, need);
             if (need > (uint32_t)kBvhStackMax)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--spp", type=int)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--kernel", default="queue", choices=["queue", "fused", "wavefront", "wavefront_classes", "auto"])
+    ap.add_argument("--count", action="store_true", help="one more launch that tallies the walks: node steps and leaf tests per segment")
     ap.add_argument("cases", nargs="+")
     args = ap.parse_args()
     kern = {"queue": rt.KERNEL_QUEUE, "fused": rt.KERNEL_FUSED, "wavefront": rt.KERNEL_WAVEFRONT, "wavefront_classes": rt.KERNEL_WAVEFRONT | rt.KERNEL_WF_CLASSES,
@@ -51,7 +52,15 @@ def main():
             if rep:
                 best = max(best, st["samples"] / st["kernel_ms"] / 1e3)
         print(f"{tag:18s} {args.kernel:17s} {case:11s} {W}x{H} spp={spp} depth={depth} seg/sample={st['segments'] / st['samples']:.3f} "
-              f"loop occupancy {st['segments'] / max(st['lane_slots'], 1):.3f}  {best:8.0f} Msamples/s", flush=True)
+              f"loop occupancy {st['segments'] / max(st['lane_slots'], 1):.3f} stack {st['bvh_stack_entries']}  {best:8.0f} Msamples/s", flush=True)
+        if args.count:
+            ctx.frame_begin(W, H)
+            ctx.render(min(spp, 16), depth, seed=0, jitter=spp != 1, kernel=kern | rt.KERNEL_COUNT_WALKS)
+            ctx.synchronize()
+            ct = ctx.stats()
+            seg = max(ct["segments"], 1)
+            print(f"{'':18s} per segment: node steps {ct['bvh_node_steps'] / seg:.2f}, box tests {ct['bvh_box_tests'] / seg:.2f}, leaf spheres "
+                  f"{ct['bvh_sphere_tests'] / seg:.2f}, leaf rects {ct['bvh_rect_tests'] / seg:.2f}", flush=True)
 
 
 if __name__ == "__main__":

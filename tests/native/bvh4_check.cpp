@@ -66,7 +66,7 @@ static uint32_t check_node(const std::vector<DevBvhNode4>& nodes, uint32_t n, co
     return need;
 }
 
-static void run_case(const char* name, std::vector<BuildObject> objs, uint32_t ppo) {
+static void run_case_with(const char* name, std::vector<BuildObject> objs, uint32_t ppo, bool by_area) {
     std::vector<Box> boxes(objs.size());
     for (size_t i = 0; i < objs.size(); ++i) {
         objs[i].first_prim = (uint32_t)i * ppo;
@@ -78,7 +78,7 @@ static void run_case(const char* name, std::vector<BuildObject> objs, uint32_t p
     const uint32_t root2 = builder.build(objs);
     std::vector<DevBvhNode4> nodes(3);  // a tree appended behind other trees' nodes
     uint32_t need = 0;
-    const uint32_t root4 = collapse_to_four(binary, root2, nodes, &need);
+    const uint32_t root4 = collapse_to_four(binary, root2, nodes, &need, by_area);
     CHECK(root4 == 3, "root index %u", root4);
     CHECK(slots.size() == boxes.size() * ppo, "slot count");
     std::vector<int> seen(boxes.size(), 0);
@@ -112,8 +112,14 @@ static void run_case(const char* name, std::vector<BuildObject> objs, uint32_t p
         CHECK(walked2 == need, "need after renumbering %u", walked2);
         for (size_t i = 0; i < seen2.size(); ++i) CHECK(seen2[i] == 1, "after renumbering object %zu is in %d leaves", i, seen2[i]);
     }
-    std::printf("%-28s objects %7zu  binary nodes %7zu  deepest leaf %2d  four-wide nodes %7zu  stack need %2u\n", name, boxes.size(),
+    std::printf("%-28s %-8s objects %7zu  binary nodes %7zu  deepest leaf %2d  four-wide nodes %7zu  stack need %2u\n", name, by_area ? "by area" : "2 levels", boxes.size(),
                 binary.size(), builder.deepest_leaf(), nodes.size() - 3, need);
+}
+
+// both rules of collapse_to_four: two binary levels per node, and the widest interior child first
+static void run_case(const char* name, const std::vector<BuildObject>& objs, uint32_t ppo) {
+    run_case_with(name, objs, ppo, false);
+    run_case_with(name, objs, ppo, true);
 }
 
 static std::vector<BuildObject> random_objects(size_t n, uint32_t seed, int shape) {
