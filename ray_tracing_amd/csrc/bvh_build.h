@@ -320,6 +320,49 @@ inline uint32_t collapse_to_four(const std::vector<DevBvhNode>& nodes2, uint32_t
     return root4;
 }
 
+// The surface-area estimate of what a walk of the four-wide tree under `root` costs a ray that meets the root's box and is
+// stopped by nothing: node_cost = the sum over the interior nodes of area(node) / area(root) (the root counts 1), the
+// expected number of node steps; leaf_cost = the same sum over the leaf children, the expected number of leaf steps.
+inline void tree_cost(const std::vector<DevBvhNode4>& nodes, uint32_t root, double* node_cost, double* leaf_cost) {
+    auto child_area = [&](const DevBvhNode4& nd, int c, float* lo, float* hi) {
+        for (int a = 0; a < 3; ++a) { lo[a] = nd.plane[2 * a][c]; hi[a] = nd.plane[2 * a + 1][c]; }
+        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Item { uint32_t n; double area; };
+    std::vector<Item> todo;
+    double root_area = 0.0;
+    {
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        const DevBvhNode4& nd = nodes[root];
+        for (int c = 0; c < 4; ++c) {
+            if (nd.ref[c] == 0xffffffffu) continue;
+            float l[3], h[3];
+            child_area(nd, c, l, h);
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], l[a]); hi[a] = std::max(hi[a], h[a]); }
+        }
+        const double dx = (double)hi[0] - lo[0], dy = (double)hi[1] - lo[1], dz = (double)hi[2] - lo[2];
+        root_area = dx * dy + dy * dz + dz * dx;
+    }
+    *node_cost = 0.0;
+    *leaf_cost = 0.0;
+    if (!(root_area > 0.0)) return;
+    todo.push_back({root, root_area});
+    while (!todo.empty()) {
+        const Item it = todo.back();
+        todo.pop_back();
+        *node_cost += it.area / root_area;
+        const DevBvhNode4& nd = nodes[it.n];
+        for (int c = 0; c < 4; ++c) {
+            if (nd.ref[c] == 0xffffffffu) continue;
+            float l[3], h[3];
+            const double a = child_area(nd, c, l, h);
+            if (nd.ref[c] & 0x80000000u) *leaf_cost += a / root_area;
+            else todo.push_back({nd.ref[c], a});
+        }
+    }
+}
+
 // Renumbers the four-wide nodes of all hierarchies breadth first from their roots together (all roots, then all their
 // interior children, level by level), so that the nodes nearest the roots — the ones every walk visits — are the
 // first of the array, whatever number of hierarchies the scene has: a kernel can hold nodes [0, k) in LDS and tell by

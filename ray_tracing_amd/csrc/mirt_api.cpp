@@ -565,6 +565,15 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
             uint32_t need = 0;
             static const bool by_area = [] { const char* v = std::getenv("MIRT_BVH_BY_AREA"); return v ? std::atoi(v) != 0 : true; }();
             q.bvh_root = collapse_to_four(binary, root2, nodes, &need, by_area);
+            {
+                static const bool report = std::getenv("MIRT_BVH_REPORT") != nullptr;
+                if (report) {
+                    double node_cost = 0.0, leaf_cost = 0.0;
+                    tree_cost(nodes, q.bvh_root, &node_cost, &leaf_cost);
+                    std::fprintf(stderr, "mirt: hierarchy of entry %u: %zu objects, %zu four-wide nodes so far, stack need %u, expected node steps %.3f, leaf steps %.3f\n",
+                                 e, objs.size(), nodes.size(), need, node_cost, leaf_cost);
+                }
+            }
             deepest_leaf = std::max(deepest_leaf, builder.deepest_leaf());
             stack_need = std::max(stack_need, need);
             if (need > (uint32_t)kBvhStackMax)
