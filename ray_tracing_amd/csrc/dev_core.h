@@ -77,6 +77,35 @@ MIRT_DEV T reload(const __attribute__((address_space(4))) T* p) {
 #endif
     return load_const((const T*)p);
 }
+// A pointer read from memory is of no known address space to the compiler: what it addresses is fetched with flat
+// instructions, each with a 64-bit address put together in vector registers first (the node step of the variant that
+// reloads its arguments: seven 64-bit adds and three moves in front of its seven fetches). The scene's arrays are all
+// in global memory; said so once, here, the fetches are global loads from a scalar base and a 32-bit offset again.
+template <class T>
+MIRT_DEV T* in_global_memory(T* p) {
+#ifdef __HIP_DEVICE_COMPILE__
+    return (T*)(__attribute__((address_space(1))) T*)(uintptr_t)p;  // (by way of the integer: a cast between the spaces alone is folded away)
+#else
+    return p;
+#endif
+}
+MIRT_DEV DevScene in_global_memory(DevScene s) {
+    s.prims = in_global_memory(s.prims);
+    s.shade = in_global_memory(s.shade);
+    s.scan = in_global_memory(s.scan);
+    s.entries = in_global_memory(s.entries);
+    s.light_prims = in_global_memory(s.light_prims);
+    s.textures = in_global_memory(s.textures);
+    s.images = in_global_memory(s.images);
+    s.perlins = in_global_memory(s.perlins);
+    s.instances = in_global_memory(s.instances);
+    s.bvh_nodes = in_global_memory(s.bvh_nodes);
+    s.bvh_leaves = in_global_memory(s.bvh_leaves);
+    s.bvh_entries = in_global_memory(s.bvh_entries);
+    s.bvh_bounds = in_global_memory(s.bvh_bounds);
+    s.fault = in_global_memory(s.fault);
+    return s;
+}
 
 // Two floats in a register pair: + - * and fma on them are single packed instructions (v_pk_add_f32,
 // v_pk_mul_f32, v_pk_fma_f32), each half rounded exactly as the scalar operation would be.
@@ -1176,8 +1205,10 @@ MIRT_DEV float perlin_turb(const DevPerlin& pl, V3 p) {
     return fabsf(accum);
 }
 
+// `lds_perlin`: the workgroup's copy of the scene's first set of noise tables, where the kernel keeps one (nullptr
+// elsewhere; a compile-time fact to every caller).
 template <uint32_t F>
-MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 p) {
+MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 p, const DevPerlin* lds_perlin = nullptr) {
     const DevTexture& t = s.textures[tex];
     uint32_t kind = t.kind;
     if ((F & F_TEX_CHECKER) && kind == TK_CHECKER) {
@@ -1190,7 +1221,8 @@ MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 
     }
     if ((F & F_TEX_NOISE) && kind == TK_NOISE) {
         // texture.rs:64-68
-        float g = fma_(0.5f, fast_sin(fma_(t.c1[3], p.z, 10.f * perlin_turb(s.perlins[t.perlin], p))), 0.5f);
+        const float turb = (lds_perlin && t.perlin == 0u) ? perlin_turb(*lds_perlin, p) : perlin_turb(s.perlins[t.perlin], p);
+        float g = fma_(0.5f, fast_sin(fma_(t.c1[3], p.z, 10.f * turb)), 0.5f);
         return v3(g, g, g);
     }
     if ((F & F_TEX_IMAGE) && kind == TK_IMAGE) {
@@ -1315,15 +1347,15 @@ MIRT_DEV bool light_draw(const DevPrim& p, V3 origin, float xi1, float xi2, V3& 
 // Value of the material's texture at the hit (texture.rs): the colour resolved at upload when the
 // texture is a solid colour, the general evaluation otherwise.
 template <uint32_t F>
-MIRT_DEV V3 shade_color(const DevScene& s, const DevShade& m, const HitInfo& h) {
-    if ((F & (F_TEX_CHECKER | F_TEX_NOISE | F_TEX_IMAGE)) && m.tex_kind != TK_SOLID) return texture_value<F>(s, m.texture, h.u, h.v, h.p);
+MIRT_DEV V3 shade_color(const DevScene& s, const DevShade& m, const HitInfo& h, const DevPerlin* lds_perlin = nullptr) {
+    if ((F & (F_TEX_CHECKER | F_TEX_NOISE | F_TEX_IMAGE)) && m.tex_kind != TK_SOLID) return texture_value<F>(s, m.texture, h.u, h.v, h.p, lds_perlin);
     return v3(m.color);
 }
 
 // material.rs:167-175: a DiffuseLight never scatters and emits toward front_face only.
 template <uint32_t F>
-MIRT_DEV V3 emitted_radiance(const DevScene& s, const DevShade& m, const HitInfo& h) {
-    if (h.front) return shade_color<F>(s, m, h);
+MIRT_DEV V3 emitted_radiance(const DevScene& s, const DevShade& m, const HitInfo& h, const DevPerlin* lds_perlin = nullptr) {
+    if (h.front) return shade_color<F>(s, m, h, lds_perlin);
     return v3(0.f, 0.f, 0.f);
 }
 
@@ -1331,7 +1363,8 @@ MIRT_DEV V3 emitted_radiance(const DevScene& s, const DevShade& m, const HitInfo
 // Returns false when the ray is absorbed. On true, `ray` is the scattered ray and `thr` has been
 // multiplied by attenuation / divisor. `g` is the bounce's scatter stream.
 template <uint32_t F>
-MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, const HitInfo& h, Rng& g, Ray& ray, V3& thr) {
+MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, const HitInfo& h, Rng& g, Ray& ray, V3& thr,
+                      const DevPerlin* lds_perlin = nullptr) {
     uint32_t mk = m.mat_kind;
     if ((F & F_MAT_METAL) && mk == MK_METAL) {
         // material.rs:86-100
@@ -1369,14 +1402,14 @@ MIRT_DEV bool scatter(const DevScene& s, const Tables& tb, const DevShade& m, co
     if ((F & F_MAT_ISOTROPIC) && mk == MK_ISOTROPIC) {
         // material.rs:194-199
         V3 dir = fnormalize(rand_in_unit_sphere_last(g));  // the bounce's first and only draws
-        V3 att = shade_color<F>(s, m, h);
+        V3 att = shade_color<F>(s, m, h, lds_perlin);
         ray.o = h.p;
         ray.d = dir;
         thr = cmul(thr, att);
         return true;
     }
     // Lambertian — material.rs:51-61 with the mixture of renderer.rs:207-221
-    V3 att = shade_color<F>(s, m, h);
+    V3 att = shade_color<F>(s, m, h, lds_perlin);
     V3 dir;
     float pdf_val;
     if (s.n_lights == 0) {

@@ -185,7 +185,7 @@ struct DevScene {
     const float* bvh_bounds;
     uint32_t n_bvh_entries;
     uint32_t n_prims, n_entries, n_lights, n_media;
-    uint32_t n_instances, n_textures;
+    uint32_t n_instances, n_textures, n_perlins;
     uint32_t features;
     float background[3];
     // Device-side diagnostics. `fault` points at one word the kernels OR bits into when they meet a state the host

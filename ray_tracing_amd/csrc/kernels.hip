@@ -306,6 +306,17 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     __shared__ DevInstance s_inst[LDS_TABLES ? kLdsInstances : 1];
     __shared__ DevPrim s_lights[LDS_TABLES ? kLdsLights : 1];
     uint32_t* stack = bvh_stack + threadIdx.x;
+    // The scene's first set of noise tables (perlin.rs:9-21: 256 gradients and three permutations, 4 864 bytes): an
+    // evaluation of the marble texture is seven octaves of three dependent fetches each, taken by the few lanes of a wave that hit the textured surface while the others wait — from LDS they come back in a fifth of
+    // the time of the vector L1.
+    constexpr bool kLdsPerlin = (F & F_TEX_NOISE) != 0 && !LDS_TABLES;
+    __shared__ __align__(16) uint32_t s_perlin[kLdsPerlin ? sizeof(DevPerlin) / 4 : 4];
+    if (kLdsPerlin && a.scene.n_perlins != 0u) {
+        const uint32_t* const src = reinterpret_cast<const uint32_t*>(a.scene.perlins);
+        for (uint32_t i = threadIdx.x; i < sizeof(DevPerlin) / 4; i += kBlock) s_perlin[i] = src[i];
+        __syncthreads();
+    }
+    const DevPerlin* const lds_perlin = kLdsPerlin ? reinterpret_cast<const DevPerlin*>(s_perlin) : nullptr;
 
     Tables tb;
     if (LDS_TABLES) {
@@ -330,12 +341,12 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     constexpr bool kReloadArgs = (F & (F_TEX_NOISE | F_TEX_IMAGE)) != 0;
     const __attribute__((address_space(4))) RenderArgs* const ka = (const __attribute__((address_space(4))) RenderArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     auto scene_now = [&]() -> DevScene {
-        if constexpr (kReloadArgs) return reload(&ka->scene);
+        if constexpr (kReloadArgs) return in_global_memory(reload(&ka->scene));
         else return a.scene;
     };
     auto tables_now = [&]() -> Tables {
         if constexpr (kReloadArgs && !LDS_TABLES) {
-            const DevScene sc = reload(&ka->scene);
+            const DevScene sc = in_global_memory(reload(&ka->scene));
             return Tables{sc.prims, sc.shade, sc.instances, sc.light_prims};
         } else {
             return tb;
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     auto next_pixel = [&q, &alive, &xy, &pixel, &sample, &sample_end, &acc, &a, ka](bool need) {
         if (__ballot(need) == 0) return;
         (void)ka;
-        uint32_t* const work_counter = MIRT_ITEM_ARG(work_counter);
+        uint32_t* const work_counter = in_global_memory(MIRT_ITEM_ARG(work_counter));
         const uint32_t width = MIRT_ITEM_ARG(width), height = MIRT_ITEM_ARG(height), spp_begin = MIRT_ITEM_ARG(spp_begin);
         const uint32_t spp_last = spp_begin + MIRT_ITEM_ARG(spp_count), chunk_spp = MIRT_ITEM_ARG(chunk_spp), n_chunks = MIRT_ITEM_ARG(n_chunks);
         const uint32_t tiles_x = (width + 7u) / 8u, n_tiles = tiles_x * ((height + 7u) / 8u);
@@ -433,8 +444,8 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         const uint32_t spp_begin = MIRT_ITEM_ARG(spp_begin), chunk_spp = MIRT_ITEM_ARG(chunk_spp), n_chunks = MIRT_ITEM_ARG(n_chunks);
         const uint32_t n_pixels = MIRT_ITEM_ARG(width) * MIRT_ITEM_ARG(height);
         const float spp_count = (float)MIRT_ITEM_ARG(spp_count);
-        float4* const accum = MIRT_ITEM_ARG(accum);
-        float4* const partial = MIRT_ITEM_ARG(partial);
+        float4* const accum = in_global_memory(MIRT_ITEM_ARG(accum));
+        float4* const partial = in_global_memory(MIRT_ITEM_ARG(partial));
         (void)ka;
         const uint32_t chunk = (sample_end - 1u - spp_begin) / chunk_spp;
 #ifdef MIRT_DEBUG_HOOKS
@@ -548,7 +559,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
                 m = tbn.shade[prim];
                 h = finalize_hit<F>(tbn, ray, t, prim, m.tex_kind == TK_IMAGE);
                 if ((F & F_MAT_LIGHT) && m.mat_kind == MK_DIFFUSE_LIGHT) {
-                    e = cmul(thr, emitted_radiance<F>(scene_now(), m, h));
+                    e = cmul(thr, emitted_radiance<F>(scene_now(), m, h, lds_perlin));
                     ended = true;
                 }
             }
@@ -575,7 +586,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         g.init_with_block0(pixel, sample, r_bounce, r_stream, a.seed, w0, w1, w2, w3);
 
         if (ready && alive && !ended) {
-            const bool cont = scatter<F>(scene_now(), tables_now(), m, h, g, ray, thr);
+            const bool cont = scatter<F>(scene_now(), tables_now(), m, h, g, ray, thr, lds_perlin);
             ++bounce;
             // absorbed, or renderer.rs:198-200: the next level returns 0. The sample is complete; its lane sits
             // out the trace of the next iteration and gets there what every path that ends gets: the item

@@ -689,6 +689,7 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     s.n_media = n_media;
     s.n_instances = (uint32_t)insts.size();
     s.n_textures = d->n_textures;
+    s.n_perlins = d->n_perlins;
     s.features = features;
     for (int a = 0; a < 3; ++a) s.background[a] = d->background[a];
     s.fault = fault_word(c);
