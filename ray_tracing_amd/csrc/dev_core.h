@@ -875,11 +875,26 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w,
     float4 px, qx, py, qy, pz, qz;
     uint4 refs;
     if (top && w.ref < s.lds_nodes) {
+#ifdef __HIP_DEVICE_COMPILE__
+        // (`top` arrives as a pointer of no known address space; the low half of such a pointer into LDS is the LDS
+        // address, and with it the fetches are LDS reads instead of flat ones with 64-bit addresses)
+        typedef const __attribute__((address_space(3))) char* LdsBytes;
+        typedef const __attribute__((address_space(3))) float4* LdsQuad;
+        LdsBytes const n = (LdsBytes)(uintptr_t)top + w.ref * kLdsNodeStride;
+        px = *(LdsQuad)(n + sx); qx = *(LdsQuad)(n + (sx ^ 16u));
+        py = *(LdsQuad)(n + sy); qy = *(LdsQuad)(n + (sy ^ 16u));
+        pz = *(LdsQuad)(n + sz); qz = *(LdsQuad)(n + (sz ^ 16u));
+        refs = *(const __attribute__((address_space(3))) uint4*)(n + 96u);
+        // (keeps the compiler from merging these fetches with the other branch's into one set of flat loads behind the
+        // branches, each with an address of either kind chosen by selects)
+        asm volatile("" : "+v"(refs.x));
+#else
         const char* const n = reinterpret_cast<const char*>(top) + w.ref * kLdsNodeStride;
         px = *reinterpret_cast<const float4*>(n + sx); qx = *reinterpret_cast<const float4*>(n + (sx ^ 16u));
         py = *reinterpret_cast<const float4*>(n + sy); qy = *reinterpret_cast<const float4*>(n + (sy ^ 16u));
         pz = *reinterpret_cast<const float4*>(n + sz); qz = *reinterpret_cast<const float4*>(n + (sz ^ 16u));
         refs = *reinterpret_cast<const uint4*>(n + 96u);
+#endif
     } else {
         px = *reinterpret_cast<const float4*>(nodes + ax); qx = *reinterpret_cast<const float4*>(nodes + (ax ^ 16u));
         py = *reinterpret_cast<const float4*>(nodes + ay); qy = *reinterpret_cast<const float4*>(nodes + (ay ^ 16u));
