@@ -1247,7 +1247,7 @@ MIRT_DEV V3 texture_value(const DevScene& s, uint32_t tex, float u, float v, V3 
         float cu = fminf(fmaxf(u, 0.f), 1.f), cv = fminf(fmaxf(v, 0.f), 1.f);
         uint32_t x = min((uint32_t)(cu * (float)im.width), im.width - 1);
         uint32_t y = min((uint32_t)(cv * (float)im.height), im.height - 1);
-        uchar4 px = reinterpret_cast<const uchar4*>(im.rgba)[(size_t)y * im.width + x];
+        uchar4 px = in_global_memory(reinterpret_cast<const uchar4*>(im.rgba))[(size_t)y * im.width + x];
         const float sc = 1.f / 255.f;
         return v3((float)px.x * sc, (float)px.y * sc, (float)px.z * sc);
     }
