@@ -2,6 +2,7 @@
 seeded inputs. Because both sides address their random draws the same way (Philox key = pixel, sample;
 counter = block, bounce, stream, seed), a path on the GPU follows the same decisions as in the oracle
 and differs only by the last bits of sin / cos / log / division; the tolerances below are for that."""
+import ctypes as C
 import math
 
 import numpy as np
@@ -733,3 +734,38 @@ def test_world_box_of_a_small_hierarchy_loses_no_hit(rt, oracle, earth):
     assert not cluster.any(), (int(cluster.sum()), rays[cluster][:3], oi[cluster][:3], gi[cluster][:3])
     hit = oi >= 0
     np.testing.assert_allclose(gt[hit], ot[hit], rtol=1e-5)
+
+
+def test_second_set_of_noise_tables(rt):
+    """The persistent kernel keeps the scene's first set of noise tables (perlin.rs:9-21) in LDS and reads any other set
+    from global memory. `2psp` with a second set in front of its own, and its texture pointed at index 1, must render
+    the image of the unchanged scene bit for bit — through the other fetch path."""
+    w, h = 48, 27
+    images = []
+    for second in (False, True):
+        sc = rt.select_scene("2psp")
+        d = sc.desc
+        keep = None
+        if second:
+            assert d.n_perlins == 1
+            keep = (rt.mirt_perlin * 2)()
+            C.memmove(C.addressof(keep[1]), C.addressof(d.perlins[0]), C.sizeof(rt.mirt_perlin))   # [0] stays all zero
+            d.perlins = C.cast(keep, C.POINTER(rt.mirt_perlin))
+            d.n_perlins = 2
+            moved = 0
+            for i in range(d.n_textures):
+                if d.textures[i].kind == 2:      # TK_NOISE
+                    d.textures[i].perlin = 1
+                    moved += 1
+            assert moved >= 1
+        ctx = rt.Context(0)
+        ctx.scene_upload(sc)
+        ctx.camera_set(rt.Camera.select_camera(w / h, "2psp"))
+        ctx.frame_begin(w, h)
+        ctx.render(6, 50, seed=3, kernel=rt.KERNEL_QUEUE)
+        st = ctx.stats()
+        assert st["device_faults"] == 0
+        images.append(ctx.read_accum())
+        del keep
+    assert np.isfinite(images[0]).all() and images[0][..., :3].std() > 0.01
+    assert (images[0] == images[1]).all()
