@@ -335,10 +335,11 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     // ends, the camera when a path starts, the scene's tables once per phase of an iteration — instead of holding them
     // in scalar registers for the whole loop: it has far more live scalars than registers, and what does not fit is
     // spilled to vector-register lanes, v_readlane / v_writelane, which compete with the arithmetic for issue slots
-    // (342 of them in its code; 60 with the reloads; `final` +5 %). The smaller variants fit or nearly fit and lose
-    // 1-2 % to the scalar loads' latency (measured per group of arguments, profiles/r3): they keep their arguments in
-    // registers.
-    constexpr bool kReloadArgs = (F & (F_TEX_NOISE | F_TEX_IMAGE)) != 0;
+    // (342 of them in its code; 60 with the reloads; `final` +5 %). The hierarchy forms of the smaller variants do the
+    // same (some 90 lane reads per iteration otherwise: `random` +1.9 %, 10^6 spheres +1.6 % — once the reloaded
+    // pointers were known to be global memory, see in_global_memory; with flat fetches behind them the reloads lost
+    // 1-2 % there). The list forms fit and keep their arguments in registers.
+    constexpr bool kReloadArgs = (F & (F_TEX_NOISE | F_TEX_IMAGE)) != 0 || (!LDS_TABLES && (F & F_BVH) != 0);
     const __attribute__((address_space(4))) RenderArgs* const ka = (const __attribute__((address_space(4))) RenderArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     auto scene_now = [&]() -> DevScene {
         if constexpr (kReloadArgs) return in_global_memory(reload(&ka->scene));
