@@ -37,9 +37,9 @@ class BvhBuilder {
     uint32_t build(std::vector<BuildObject>& objs) {
         const size_t n = objs.size(), node0 = nodes_.size(), slot0 = slots_.size();
         slots_.resize(slot0 + n * ppo_);
-        if (n == 1) {
+        if (is_leaf(n)) {
             // the whole entry is one leaf: root with a single child
-            Ref r = recurse(objs, 0, 1, 1, node0, slot0, 0);
+            Ref r = recurse(objs, 0, n, 1, node0, slot0, 0);
             DevBvhNode nd{};
             set_child(nd, 0, r);
             Ref none;
@@ -87,6 +87,13 @@ class BvhBuilder {
             nd.ref1 = ref;
         }
     }
+    // A range of this many objects becomes one leaf. One object per leaf unless MIRT_BVH_LEAF asks for more (measurement
+    // runs; single-primitive objects only, at most 16 records). The node numbering leaves the nodes such a range would
+    // have had unused.
+    bool is_leaf(size_t n) const {
+        static const size_t leaf_max = [] { const char* v = std::getenv("MIRT_BVH_LEAF"); long l = v ? std::atol(v) : 1; return (size_t)std::min(std::max(l, 1l), 16l); }();
+        return n == 1 || (ppo_ == 1 && n <= leaf_max);
+    }
     static float area(const float* lo, const float* hi) {
         float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
         return 2.f * (dx * dy + dy * dz + dz * dx);
@@ -112,12 +119,13 @@ class BvhBuilder {
                 chi[a] = std::max(chi[a], c);
             }
         size_t n = end - begin;
-        if (n == 1) {
+        if (is_leaf(n)) {
             int seen = deepest_.load();
             while (seen < depth && !deepest_.compare_exchange_weak(seen, depth)) {}
             r.c = (uint32_t)slot;
-            r.n = ppo_;
-            for (uint32_t q = 0; q < ppo_; ++q) slots_[slot + q] = objs[begin].first_prim + q;
+            r.n = (uint32_t)n * ppo_;
+            for (size_t o = 0; o < n; ++o)
+                for (uint32_t q = 0; q < ppo_; ++q) slots_[slot + o * ppo_ + q] = objs[begin + o].first_prim + q;
             return r;
         }
         size_t mid = begin;

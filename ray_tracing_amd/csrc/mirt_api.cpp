@@ -547,10 +547,10 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
             bool cuboids = q.prims_per_object == 6;
             for (uint32_t j = 0; cuboids && j < objs.size(); ++j) cuboids = is_cuboid(d->prims + objs[j].first_prim);
             const uint32_t records_per_object = cuboids ? 1u : q.prims_per_object;
-            // One object per leaf (the builder's rule): measured against 2 / 3 / 4 / 6 spheres per leaf — 1 765 /
-            // 1 648 / 1 548 / 1 447 / 1 271 Msamples/s on `random`, 705 / 653 / 608 / 563 / 506 on 1 M spheres (a
-            // leaf test costs a step whether or not the ray comes near the second sphere; the box test that
-            // replaces it is cheaper).
+            // One object per leaf (the builder's rule; MIRT_BVH_LEAF=n for measurement runs). On the four-wide trees 2 / 3 / 4
+            // objects per leaf measured `random` 3 050 -> 2 815 / 2 475 / 2 225 Msamples/s, 10^6 spheres 1 290 -> 1 110 / 975 /
+            // 845, `final` 2 705 -> 2 500 / 2 325 / 2 190: half a node step saved per segment against one and a half more
+            // sphere tests, each a dependent fetch of its own (the box test that replaces it is a lane of the node step).
             if (records_per_object > 16u) return bad("entry " + std::to_string(e) + ": prims_per_object is limited to 16");
             // Box padding for walk_node's fused plane distances: 2^-21 of the largest coordinate magnitude of the
             // hierarchy (the evaluation errs by 2^-24 |origin| in position for origins inside the scene; farther

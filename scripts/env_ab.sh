@@ -7,7 +7,7 @@ out=gpurun_out/env_ab_$var.txt
 for rep in 1 2; do
   for v in ${VALUES:-0 1}; do
     echo "# $var=$v" >> $out
-    env $var=$v timeout -k 10 300 python scripts/ab.py --reps 2 ${CASES:-random final256 million million4} >> $out 2>&1 || exit 1
+    env $var=$v timeout -k 10 300 python scripts/ab.py --reps 2 $AB_FLAGS ${CASES:-random final256 million million4} >> $out 2>&1 || exit 1
   done
 done
 cat $out
