@@ -101,6 +101,7 @@ MIRT_DEV DevScene in_global_memory(DevScene s) {
     s.instances = in_global_memory(s.instances);
     s.bvh_nodes = in_global_memory(s.bvh_nodes);
     s.bvh_leaves = in_global_memory(s.bvh_leaves);
+    s.bvh_leaf_moving = in_global_memory(s.bvh_leaf_moving);
     s.bvh_entries = in_global_memory(s.bvh_entries);
     s.bvh_bounds = in_global_memory(s.bvh_bounds);
     s.fault = in_global_memory(s.fault);
@@ -943,15 +944,18 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w,
 }
 
 // One primitive record of a leaf (the record's kind differs from lane to lane, so the rectangle's axes
-// are chosen with per-lane selects). Same tests as the list scan: geo.rs:89-105, geo.rs:196-204.
+// are chosen with per-lane selects). Same tests as the list scan: geo.rs:89-105, geo.rs:196-204. `mv` is the
+// DevLeafMoving beside the record (read only for a moving sphere).
 template <uint32_t F>
-MIRT_DEV bool leaf_rec_hit(const DevScene& s, const DevLeafRec& rec, const LRay& l, float t_min, float t_max, float& t_out) {
+MIRT_DEV bool leaf_rec_hit(const DevLeafRec& rec, const DevLeafMoving& mv, const LRay& l, float t_min, float t_max, float& t_out) {
     const uint32_t code = rec.code_inst & 0xffu;
     if ((F & F_SPHERE) && (!(F & (F_RECT | F_MOVING)) || code == SC_SPHERE))
         return sphere_hit_c(v3(rec.f), rec.f[3], l.r, t_min, t_max, t_out);
     if ((F & F_MOVING) && code == SC_SPHERE_MOVING) {
-        const DevPrim& q = s.prims[rec.prim];
-        return sphere_hit_c(sphere_center<F>(q, l.r.time), q.a[3], l.r, t_min, t_max, t_out);
+        // geo.rs:29-33, the expression of sphere_center
+        const V3 c0 = v3(rec.f), c1 = v3(mv.center1);
+        const V3 center = c0 + (l.r.time - mv.time0) / (mv.time1 - mv.time0) * (c1 - c0);
+        return sphere_hit_c(center, rec.f[3], l.r, t_min, t_max, t_out);
     }
     if ((F & F_RECT) && code >= SC_RECT_XY && code <= SC_RECT_YZ) {
         uint32_t xi, yi, zi;
@@ -965,12 +969,46 @@ MIRT_DEV bool leaf_rec_hit(const DevScene& s, const DevLeafRec& rec, const LRay&
     return false;
 }
 
+// A leaf's 32-byte record — and, where the scene has moving spheres in a hierarchy, the 32 bytes beside it — fetched
+// whole, as 16-byte loads issued together, into values: a record read field by field through a reference is fetched
+// piece by piece where the pieces are used — the kind first, the rest behind the branch on the kind, a moving sphere's
+// primitive behind that — each a round trip to memory of its own in a step that consists of little else.
+template <bool WITH_MOVING>
+MIRT_DEV void load_leaf_record(const DevLeafRec* p, const DevLeafMoving* pm, DevLeafRec& rec, DevLeafMoving& mv) {
+    union {
+        DevLeafRec value;
+        uint4 quads[2];
+    } u;
+    union {
+        DevLeafMoving value;
+        uint4 quads[2];
+    } um;
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    u.quads[0] = q[0];
+    u.quads[1] = q[1];
+    um.quads[0] = um.quads[1] = make_uint4(0u, 0u, 0u, 0u);
+    if (WITH_MOVING && pm) {  // (the same pointer in every lane)
+        const uint4* qm = reinterpret_cast<const uint4*>(pm);
+        um.quads[0] = qm[0];
+        um.quads[1] = qm[1];
+    }
+#ifdef __HIP_DEVICE_COMPILE__
+    // (the values are complete here: the compiler may not move a quad's fetch down into the branch that reads it)
+    if (WITH_MOVING) asm volatile("" : "+v"(u.quads[0].x), "+v"(u.quads[1].x), "+v"(um.quads[0].x), "+v"(um.quads[1].x));
+    else asm volatile("" : "+v"(u.quads[0].x), "+v"(u.quads[1].x));
+#endif
+    rec = u.value;
+    mv = um.value;
+}
+
 // The records of one leaf, in object order (a later record wins a tie, as in ray.rs:123-133).
 template <uint32_t F>
 MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w, const uint32_t* stack, uint32_t stride, uint32_t& tally) {
     const uint32_t first = w.ref & kRefLeafIndexMask, n = ((w.ref >> 27) & 15u) + 1u;
     for (uint32_t j = 0; j < n; ++j) {
-        const DevLeafRec& rec = s.bvh_leaves[first + j];
+        DevLeafRec rec;
+        DevLeafMoving mv;
+        load_leaf_record<(F & F_MOVING) != 0>(s.bvh_leaves + first + j, s.bvh_leaf_moving ? s.bvh_leaf_moving + first + j : nullptr, rec, mv);
         if ((F & F_RECT) && (rec.code_inst & 0xffu) == SC_CUBOID) {
             tally += 6u * kTallyRect;
             // Cuboid (geo.rs:245-289): its six rects in list order — XY at z lo / hi, XZ at y lo / hi, YZ at
@@ -984,7 +1022,7 @@ MIRT_DEV void walk_leaf(const DevScene& s, float t_min, const LRay& lr, Walk& w,
         const uint32_t code = rec.code_inst & 0xffu;
         tally += ((F & F_RECT) && code >= SC_RECT_XY && code <= SC_RECT_YZ) ? kTallyRect : kTallySphere;
         float t;
-        if (leaf_rec_hit<F>(s, rec, lr, t_min, w.closest, t)) {
+        if (leaf_rec_hit<F>(rec, mv, lr, t_min, w.closest, t)) {
             w.closest = t;
             w.best = (int)rec.prim;
         }

@@ -48,6 +48,16 @@ struct __attribute__((aligned(32))) DevLeafRec {
     float f[6];
 };
 static_assert(sizeof(DevLeafRec) == 32, "DevLeafRec is two 16-byte loads");
+// What a moving sphere's leaf record needs beside its first centre and radius (geo.rs:25-33), at the record's index in
+// an array of its own (DevScene::bvh_leaf_moving; only scenes with a moving sphere in a hierarchy have the array): the
+// record and this are fetched together, where reading the primitive through the record's index took three dependent
+// fetches more.
+struct __attribute__((aligned(32))) DevLeafMoving {
+    float center1[3];
+    float time0, time1;
+    float pad[3];
+};
+static_assert(sizeof(DevLeafMoving) == 32, "DevLeafMoving is two 16-byte loads");
 
 // One element of a list scan (64 bytes = one s_load_dwordx16; the scan index is wave-uniform, so the
 // record stays in scalar registers). A list (world entry or the boundary of a medium) is a contiguous
@@ -177,6 +187,7 @@ struct DevScene {
     const DevInstance* instances;
     const DevBvhNode4* bvh_nodes;
     const DevLeafRec* bvh_leaves;  // leaf primitive records in tree order
+    const DevLeafMoving* bvh_leaf_moving;  // beside them, or nullptr when no leaf record is a moving sphere
     const uint32_t* bvh_entries;   // indices into entries of the EK_BVH ones, in world order
     // World-space boxes of the hierarchies that are small against the scene (two float4 per hierarchy, bvh_entries
     // order: low corner with a flag in .w — 1 = test this box before starting the hierarchy — and high corner), padded;

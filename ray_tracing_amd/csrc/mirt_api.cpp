@@ -599,9 +599,18 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     if (slots.size() >= (1u << 27) - 1u) return bad("too many hierarchy members");
     if (nodes.size() >= (1u << 25)) return bad("too many hierarchy nodes (a walk addresses a node by a 32-bit byte offset: at most 2^25 nodes of 128 bytes)");
     std::vector<DevLeafRec> leaves(slots.size());
+    std::vector<DevLeafMoving> leaf_moving;   // beside the records, only when one of them is a moving sphere
     for (size_t i = 0; i < slots.size(); ++i) {
         if (!slot_is_cuboid[i]) {
             leaves[i] = scan_record(slots[i]);
+            if ((leaves[i].code_inst & 0xffu) == SC_SPHERE_MOVING) {
+                const mirt_prim& p = d->prims[slots[i]];
+                leaf_moving.resize(slots.size());
+                DevLeafMoving& m = leaf_moving[i];
+                for (int a = 0; a < 3; ++a) m.center1[a] = p.center1[a];
+                m.time0 = p.time0;
+                m.time1 = p.time1;
+            }
             continue;
         }
         const mirt_prim* p = d->prims + slots[i];  // XY(z lo), XY(z hi), XZ(y lo), XZ(y hi), YZ(x lo), YZ(x hi)
@@ -654,6 +663,8 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     c->n_bvh_nodes = (uint32_t)nodes.size();
     c->n_scan_records = (uint32_t)scan.size() - 1u;  // without the SC_END record
     if ((rc = upload(c, leaves, &s.bvh_leaves))) return rc;
+    s.bvh_leaf_moving = nullptr;
+    if (!leaf_moving.empty() && (rc = upload(c, leaf_moving, &s.bvh_leaf_moving))) return rc;
     std::vector<uint32_t> bvh_entries;
     for (uint32_t e = 0; e < d->n_world; ++e)
         if (entries[e].kind == EK_BVH) bvh_entries.push_back(e);
