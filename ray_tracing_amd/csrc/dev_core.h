@@ -103,6 +103,7 @@ MIRT_DEV DevScene in_global_memory(DevScene s) {
     s.bvh_leaves = in_global_memory(s.bvh_leaves);
     s.bvh_leaf_moving = in_global_memory(s.bvh_leaf_moving);
     s.bvh_entries = in_global_memory(s.bvh_entries);
+    s.bvh_starts = in_global_memory(s.bvh_starts);
     s.bvh_bounds = in_global_memory(s.bvh_bounds);
     s.fault = in_global_memory(s.fault);
     return s;
@@ -756,11 +757,26 @@ struct Walk {
 // The ray in the frame of hierarchy number k (world order). It is derived from the path's ray whenever a walk
 // starts or resumes instead of being carried in `Walk`: a walk that pauses over the shading code of an
 // iteration then holds five registers, not fifteen.
+MIRT_DEV DevBvhStart walk_start(const DevScene& s, uint32_t k) {
+    // a scene with one hierarchy: the same record for every lane, a scalar load
+    if (s.n_bvh_entries == 1u) return load_const(s.bvh_starts);
+    union {
+        DevBvhStart value;
+        uint4 quads[2];
+    } u;
+    const uint4* q = reinterpret_cast<const uint4*>(s.bvh_starts + k);
+    u.quads[0] = q[0];
+    u.quads[1] = q[1];
+#ifdef __HIP_DEVICE_COMPILE__
+    asm volatile("" : "+v"(u.quads[0].x), "+v"(u.quads[1].x));  // (whole here: no fetch moved into a branch)
+#endif
+    return u.value;
+}
 template <uint32_t F>
-MIRT_DEV LRay walk_ray(const DevScene& s, const Ray& r, uint32_t k) {
-    const DevEntry& en = s.entries[s.bvh_entries[k]];
+MIRT_DEV LRay walk_ray(const Ray& r, const DevBvhStart& st) {
     // 1-ulp reciprocals; walk_node() widens the far bound by more than that
-    LRay l = make_lray(((F & F_INSTANCE) && en.instance) ? to_local(s.instances[en.instance], r) : r);
+    const DevInstance frame{st.sin_t, st.cos_t, st.ox, st.oy, st.oz, 0.f, 0.f, 0.f};
+    LRay l = make_lray(((F & F_INSTANCE) && st.instance) ? to_local(frame, r) : r);
     // A direction component of (+-)0 has the reciprocal +-inf, and walk_node's  p * rinv + (-origin * rinv)  would
     // be inf - inf = NaN for every plane on the far side of the origin: min / max drop the NaN and a slab the ray
     // lies inside is taken for one it misses. With the reciprocal limited to +-2^100 the two products stay finite
@@ -787,8 +803,9 @@ MIRT_DEV uint32_t walk_count(const DevScene& s, const Ray& r) {
 template <uint32_t F>
 MIRT_DEV void walk_begin(const DevScene& s, const Ray& r, Walk& w, LRay& lr) {
     const uint32_t k = w.next++;
-    lr = walk_ray<F>(s, r, k);
-    w.ref = s.entries[s.bvh_entries[k]].bvh_root;
+    const DevBvhStart st = walk_start(s, k);
+    lr = walk_ray<F>(r, st);
+    w.ref = st.root;
     w.sp = 0;
 }
 
@@ -1079,7 +1096,7 @@ MIRT_DEV bool walk_some(const DevScene& s, const Ray& r, float t_min, Walk& w, u
         tally = 0;
     };
     LRay lr = make_lray(r);
-    if (w.ref != kWalkIdle) lr = walk_ray<F>(s, r, w.next - 1u);  // resuming inside hierarchy w.next - 1
+    if (w.ref != kWalkIdle) lr = walk_ray<F>(r, walk_start(s, w.next - 1u));  // resuming inside hierarchy w.next - 1
     for (;;) {
         if (s.bvh_bounds && w.ref == kWalkIdle) walk_skip_missed(s, r, t_min, w, n);
         if (w.ref == kWalkIdle && w.next < n) walk_begin<F>(s, r, w, lr);
@@ -1149,7 +1166,24 @@ template <uint32_t F>
 // `need_uv`: the surface's texture reads u, v (only image textures do); the record keeps 0, 0 otherwise, so the
 // many hits that never look at them do not pay for acos / atan2.
 MIRT_DEV HitInfo finalize_hit(const Tables& tb, const Ray& r, float t, int prim, bool need_uv = true) {
-    const DevPrim& p = tb.prims[prim];
+    // (the variants with hierarchies read the primitive from global memory: whole, its three quads fetched together —
+    // field by field a moving sphere is three dependent fetches, flags, then second centre, then radius)
+    DevPrim whole;
+    if constexpr ((F & F_BVH) != 0) {
+        union {
+            DevPrim value;
+            uint4 quads[3];
+        } u;
+        const uint4* q = reinterpret_cast<const uint4*>(tb.prims + prim);
+        u.quads[0] = q[0];
+        u.quads[1] = q[1];
+        u.quads[2] = q[2];
+#ifdef __HIP_DEVICE_COMPILE__
+        asm volatile("" : "+v"(u.quads[0].x), "+v"(u.quads[1].x), "+v"(u.quads[2].x));
+#endif
+        whole = u.value;
+    }
+    const DevPrim& p = (F & F_BVH) ? whole : tb.prims[prim];
     HitInfo h;
     h.u = 0.f;
     h.v = 0.f;

@@ -121,7 +121,7 @@ template <uint32_t F>
 MIRT_DEV void pool_submit(const DevScene& s, const Pool& p, const PoolState& st, bool pred, const Ray& r, float closest, int best) {
     const uint32_t slot = threadIdx.x;
     if (pred) {
-        const LRay lr = walk_ray<F>(s, r, 0u);
+        const LRay lr = walk_ray<F>(r, walk_start(s, 0u));
         const uint32_t ref = s.entries[s.bvh_entries[0]].bvh_root;
         p.a[slot] = make_float4(lr.rinv.x, lr.rinv.y, lr.rinv.z, closest);
         p.b[slot] = make_float4(lr.nc.x, lr.nc.y, lr.nc.z, __uint_as_float(ref));
@@ -184,7 +184,7 @@ MIRT_DEV void pool_leaf_chunk(const DevScene& s, const Pool& p, uint32_t cur, ui
         started = (m >> 8) & 0xffu;
         if (w.ref == kWalkIdle) {
             // walk_begin for hierarchy number `started`
-            const LRay lr = walk_ray<F>(s, r, started);
+            const LRay lr = walk_ray<F>(r, walk_start(s, started));
             w.ref = s.entries[s.bvh_entries[started]].bvh_root;
             w.sp = 0;
             ++started;

@@ -36,7 +36,7 @@ static_assert(sizeof(DevPrim) == 48, "DevPrim is three 16-byte quads");
 
 // One primitive of a hierarchy leaf (32 bytes, two 16-byte vector loads per lane).
 //   rect:   f = (k, lo0, hi0, lo1, hi1, -)      sphere: f = (center.xyz, radius, -, -)
-//   moving sphere: data comes from prims[prim]
+//   moving sphere: f = (center0.xyz, radius, -, -), the rest in DevLeafMoving (list scans read prims[prim])
 enum : uint32_t {
     SC_SPHERE = 0, SC_RECT_XY = 1, SC_RECT_XZ = 2, SC_RECT_YZ = 3, SC_MEDIUM = 4, SC_SPHERE_MOVING = 5, SC_END = 6,
     SC_RECT2_XY = 7, SC_RECT2_XZ = 8, SC_RECT2_YZ = 9,  // two consecutive rects of one axis (scan records only)
@@ -92,6 +92,17 @@ struct __attribute__((aligned(16))) DevInstance {
     float sin_t, cos_t, ox, oy;
     float oz, pad0, pad1, pad2;
 };
+
+// What a walk needs to start hierarchy k of the scene (world order): its root node and the frame of its entry
+// (`instance` = 0: none), in one 32-byte record — through bvh_entries, entries and instances it was three dependent
+// fetches at the start of every hierarchy, and again whenever a walk continued in a later iteration.
+struct __attribute__((aligned(32))) DevBvhStart {
+    float sin_t, cos_t, ox, oy, oz;
+    uint32_t root;
+    uint32_t instance;
+    uint32_t pad;
+};
+static_assert(sizeof(DevBvhStart) == 32, "DevBvhStart is two 16-byte loads");
 
 struct __attribute__((aligned(16))) DevTexture {
     uint32_t kind, perlin, image, pad;
@@ -189,6 +200,7 @@ struct DevScene {
     const DevLeafRec* bvh_leaves;  // leaf primitive records in tree order
     const DevLeafMoving* bvh_leaf_moving;  // beside them, or nullptr when no leaf record is a moving sphere
     const uint32_t* bvh_entries;   // indices into entries of the EK_BVH ones, in world order
+    const DevBvhStart* bvh_starts; // one per hierarchy, same order
     // World-space boxes of the hierarchies that are small against the scene (two float4 per hierarchy, bvh_entries
     // order: low corner with a flag in .w — 1 = test this box before starting the hierarchy — and high corner), padded;
     // nullptr when no hierarchy is flagged. A ray that misses the box cannot hit a member, so its walk skips the

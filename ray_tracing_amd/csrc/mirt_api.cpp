@@ -671,6 +671,22 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
     if ((rc = upload(c, bvh_entries, &s.bvh_entries))) return rc;
     s.n_bvh_entries = (uint32_t)bvh_entries.size();
     {
+        std::vector<DevBvhStart> starts(bvh_entries.size());
+        for (size_t k = 0; k < bvh_entries.size(); ++k) {
+            const DevEntry& en = entries[bvh_entries[k]];
+            DevBvhStart st{};
+            st.cos_t = 1.f;
+            if (en.instance) {
+                const DevInstance& in = insts[en.instance];
+                st.sin_t = in.sin_t; st.cos_t = in.cos_t; st.ox = in.ox; st.oy = in.oy; st.oz = in.oz;
+            }
+            st.root = en.bvh_root;
+            st.instance = en.instance;
+            starts[k] = st;
+        }
+        if ((rc = upload(c, starts, &s.bvh_starts))) return rc;
+    }
+    {
         // Hierarchies whose world box is small against the union of all of them (under an eighth of its volume, all
         // boxes finite) are tested against their box before a walk starts them (walk_skip_missed).
         std::vector<float> bounds(entry_boxes.size() * 8, 0.f);
