@@ -381,7 +381,7 @@ struct DrawKey {
 };
 
 template <uint32_t F>
-MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, float t_min, float t_max, const DrawKey& key,
+MIRT_DEV bool medium_hit(const DevScene& s, const DevScanRec& m, const Ray& r, float t_min, float t_max, const DrawKey& key,
                          float& t_out);
 
 // closest = t, best = prim in the lanes where  t_min <= t <= closest,  lo0 <= x <= hi0  and  lo1 <= y <= hi1  — the
@@ -595,14 +595,17 @@ MIRT_DEV void list_scan(const DevScene& s, uint32_t first, uint32_t count, const
             case SC_SPHERE: if (F & F_SPHERE) sphere_accept<ALLOW_MEDIUM>(v3(rec.f), rec.f[3], rec.prim, lr.r, t_min, closest, best); break;
             case SC_SPHERE_MOVING:
                 if (F & F_MOVING) {
-                    const DevPrim q = load_const(s.prims + rec.prim);
-                    sphere_accept<ALLOW_MEDIUM>(sphere_center<F>(q, lr.r.time), q.a[3], rec.prim, lr.r, t_min, closest, best);
+                    // geo.rs:29-33 (the expression of sphere_center) from the record itself: f = (centre 0, radius, centre 1,
+                    // time 0, time 1)
+                    const V3 c0 = v3(rec.f), c1 = v3(rec.f + 4);
+                    const V3 center = c0 + (lr.r.time - rec.f[7]) / (rec.f[8] - rec.f[7]) * (c1 - c0);
+                    sphere_accept<ALLOW_MEDIUM>(center, rec.f[3], rec.prim, lr.r, t_min, closest, best);
                 }
                 break;
             case SC_MEDIUM:
                 if (ALLOW_MEDIUM && (F & F_MEDIUM)) {
                     float t = 0.f;
-                    if (medium_hit<F>(s, load_const(s.prims + rec.prim), r, t_min, closest, key, t)) {
+                    if (medium_hit<F>(s, rec, r, t_min, closest, key, t)) {
                         closest = t;
                         best = (int)rec.prim;
                     }
@@ -691,15 +694,19 @@ MIRT_DEV bool cuboid_crossings(const DevScene& s, uint32_t first, const Ray& r, 
 // where its shape allows (DevPrim::b[0] of a medium, set at upload): one static sphere, or the three rect pairs of a
 // cuboid; any other boundary list is scanned twice, as the reference does.
 template <uint32_t F>
-MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, float t_min, float t_max, const DrawKey& key,
+MIRT_DEV bool medium_hit(const DevScene& s, const DevScanRec& m, const Ray& r, float t_min, float t_max, const DrawKey& key,
                          float& t_out) {
-    uint32_t bfirst = __float_as_uint(p.a[0]), bcount = __float_as_uint(p.a[1]);
-    const uint32_t shape = __float_as_uint(p.b[0]);  // wave-uniform, like the record itself
+    // The medium's scan record carries what the test needs (filled at upload from the medium's primitive and its
+    // boundary): f[0..3] the boundary sphere where the boundary is one, f[4] -1 / density, and as bits f[5] the medium's
+    // index, f[6] the boundary's shape, f[7] the boundary sphere's instance, f[8], f[9] first record and number of
+    // records of the boundary list — read through the primitive and the boundary's own record these were two more
+    // dependent loads per medium and segment.
+    const uint32_t bfirst = __float_as_uint(m.f[8]), bcount = __float_as_uint(m.f[9]);
+    const uint32_t shape = __float_as_uint(m.f[6]);  // wave-uniform, like the record itself
     float t1 = MIRT_INF, t2 = MIRT_INF;
     if ((F & F_SPHERE) && shape == MS_SPHERE) {
-        const DevScanRec rec = load_const(s.scan + bfirst);
-        const uint32_t inst = (F & F_INSTANCE) ? rec.code_inst >> 8 : 0u;
-        if (!sphere_crossings(v3(rec.f), rec.f[3], inst ? to_local(load_const(s.instances + inst), r) : r, t1, t2)) return false;
+        const uint32_t inst = (F & F_INSTANCE) ? __float_as_uint(m.f[7]) : 0u;
+        if (!sphere_crossings(v3(m.f), m.f[3], inst ? to_local(load_const(s.instances + inst), r) : r, t1, t2)) return false;
     } else if ((F & F_RECT) && shape == MS_CUBOID) {
         if (!cuboid_crossings(s, bfirst, r, t1, t2)) return false;
     } else {
@@ -715,9 +722,9 @@ MIRT_DEV bool medium_hit(const DevScene& s, const DevPrim& p, const Ray& r, floa
     if (t1 >= t2) return false;
     float distance_inside_boundary = t2 - t1;
     uint32_t w0, w1, w2, w3;
-    philox4x32_10(key.pixel, key.sample, 0u, key.bounce, STREAM_MEDIUM + __float_as_uint(p.a[3]), key.seed, w0, w1, w2, w3);
+    philox4x32_10(key.pixel, key.sample, 0u, key.bounce, STREAM_MEDIUM + __float_as_uint(m.f[5]), key.seed, w0, w1, w2, w3);
     // ln from the hardware log2 (1 ulp): the free path is a random draw, its last bit decides nothing
-    float hit_distance = p.a[2] * (__builtin_amdgcn_logf(unit_f32(w0)) * 0.6931471805599453f);
+    float hit_distance = m.f[4] * (__builtin_amdgcn_logf(unit_f32(w0)) * 0.6931471805599453f);
     if (hit_distance > distance_inside_boundary) return false;
     t_out = t1 + hit_distance;
     return true;

@@ -67,7 +67,10 @@ static_assert(sizeof(DevLeafMoving) == 32, "DevLeafMoving is two 16-byte loads")
 // with packed two-float arithmetic, so the values of the two rects are interleaved.
 //   rect:       f = (k, lo0, hi0, lo1, hi1)       sphere: f = (center.xyz, radius)
 //   rect pair:  f = (k_a, k_b, lo0_a, lo0_b, hi0_a, hi0_b, lo1_a, lo1_b, hi1_a, hi1_b); ids prim, prim2
-//   moving sphere / medium: data comes from prims[prim]
+//   moving sphere: f = (center0.xyz, radius, center1.xyz, time0, time1)
+//   medium: f[0..3] = its boundary sphere (when the boundary is one static sphere), f[4] = -1 / density, and as bits
+//           f[5] = medium index, f[6] = MS_* shape of the boundary, f[7] = the boundary sphere's instance,
+//           f[8], f[9] = first record and number of records of the boundary list
 struct __attribute__((aligned(64))) DevScanRec {
     uint32_t code_inst;  // code | instance << 8
     uint32_t prim;       // index into prims (the id reported for a hit)

@@ -318,6 +318,30 @@ static int scene_upload_impl(mirt_ctx* c, const mirt_scene_desc* d) {
             } else {
                 for (int a = 0; a < 6; ++a) r.f[a] = one.f[a];
             }
+            if (p.kind == MIRT_PRIM_SPHERE && (p.flags & MIRT_PRIM_MOVING)) {
+                for (int a = 0; a < 3; ++a) r.f[4 + a] = p.center1[a];
+                r.f[7] = p.time0;
+                r.f[8] = p.time1;
+            }
+            if (p.kind == MIRT_PRIM_MEDIUM) {
+                // (the media's primitives were completed above: boundary records, shape, index)
+                const DevPrim& q = prims[i];
+                uint32_t bfirst, shape;
+                std::memcpy(&bfirst, &q.a[0], 4);
+                std::memcpy(&shape, &q.b[0], 4);
+                for (int a = 0; a < 12; ++a) r.f[a] = 0.f;
+                r.f[4] = q.a[2];
+                r.f[5] = q.a[3];
+                r.f[6] = q.b[0];
+                r.f[8] = q.a[0];
+                r.f[9] = q.a[1];
+                if (shape == MS_SPHERE) {
+                    const DevScanRec b = scan[bfirst];
+                    for (int a = 0; a < 4; ++a) r.f[a] = b.f[a];
+                    const uint32_t inst = b.code_inst >> 8;
+                    std::memcpy(&r.f[7], &inst, 4);
+                }
+            }
             scan.push_back(r);
         }
         if (merge_cuboids) {
