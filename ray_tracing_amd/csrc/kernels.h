@@ -37,7 +37,11 @@ struct RenderArgs {
     uint32_t count_cost;        // tally the hierarchy walks' node steps and leaf tests into the statistics (slower: not for timed launches)
 };
 enum : uint32_t { LOOP_AUTO = 0, LOOP_FUSED = 1, LOOP_QUEUE = 2 };
-constexpr size_t kWorkCounterBytes = 8 * 128;  // eight counters, one per 128-byte line
+#ifndef MIRT_ITEM_COUNTERS
+#define MIRT_ITEM_COUNTERS 8
+#endif
+constexpr size_t kWorkCounterBytes = MIRT_ITEM_COUNTERS * 128;  // the item counters, one per 128-byte line
+static_assert(MIRT_ITEM_COUNTERS <= 32 && (MIRT_ITEM_COUNTERS & (MIRT_ITEM_COUNTERS - 1)) == 0, "a power of two, one bit each in ItemQueue::dead");
 // Whether launch_render_fused() renders these arguments with the persistent pixel-queue kernel.
 bool render_uses_queue(const RenderArgs& a);
 

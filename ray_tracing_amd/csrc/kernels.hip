@@ -239,11 +239,15 @@ struct ItemQueue {
     uint32_t origin;     // that tile's origin, x | y << 16
     uint32_t dead;       // bit i: counter i has passed its last tile (all kItemCounters bits: the launch has no work left)
 };
-// The tiles are dealt to kItemCounters counters (tile run r belongs to counter r mod 8, which hands out r / 8), each
-// in its own 128-byte line. A wave draws from the counter of its workgroup (blockIdx mod 8) and moves on to the
-// others when that one is exhausted. One counter for the whole device costs nothing while items are long, but
+// The tile runs are dealt to kItemCounters counters, each in its own 128-byte line: counter i hands out the i-th
+// contiguous share of them, in order. A wave draws from the counter of its workgroup (blockIdx mod 8) and moves on to
+// the others when that one is exhausted. One counter for the whole device costs nothing while items are long, but
 // with almost free samples (one sphere: 0.5 M trips in 6 ms) every trip queues behind all the others'.
-constexpr uint32_t kItemCounters = 8, kItemCounterStride = 32;  // stride in 32-bit words
+// (Contiguous shares rather than every eighth run: the runs a wave takes one after the other then lie a few tile rows
+// apart instead of a sixth of the frame, the lanes it holds at any time see the same few surfaces, and fewer waves pay
+// for a branch that one lane in fifty needs — `final` +3.3 %, `random` +1.2 %, none of the scenes slower. Sixteen or
+// thirty-two shares help `final` more, +5.5 %, and cost the 10^6-sphere pass and `smoke` 1-3 %.)
+constexpr uint32_t kItemCounters = MIRT_ITEM_COUNTERS, kItemCounterStride = 32;  // stride in 32-bit words
 
 // Hands an item to every lane with `need`: pixel position and chunk; false once the launch has none left.
 // One trip to a counter fetches one wave-load. Longer runs (fixed, or a share of what is left) were measured:
@@ -264,8 +268,9 @@ __device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* co
                 uint32_t c = 0;
                 if (lane == 0) c = atomicAdd(counters + qi * kItemCounterStride, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
-                const uint32_t r = c * kItemCounters + qi;
-                if (c < 0x1fffffffu && r < n_tiles * n_chunks) run = r;
+const uint32_t band = (n_tiles * n_chunks + kItemCounters - 1u) / kItemCounters;
+                const uint32_t r = qi * band + c;
+                if (c < band && r < n_tiles * n_chunks) run = r;
                 else q.dead |= 1u << qi;
             }
             if (run == 0xffffffffu) break;  // every counter is exhausted
@@ -307,8 +312,9 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
     __shared__ DevPrim s_lights[LDS_TABLES ? kLdsLights : 1];
     uint32_t* stack = bvh_stack + threadIdx.x;
     // The scene's first set of noise tables (perlin.rs:9-21: 256 gradients and three permutations, 4 864 bytes): an
-    // evaluation of the marble texture is seven octaves of three dependent fetches each, taken by the few lanes of a wave that hit the textured surface while the others wait — from LDS they come back in a fifth of
-    // the time of the vector L1.
+    // evaluation of the marble texture is seven octaves of three dependent fetches each, taken by the few lanes of a
+    // wave that hit the textured surface while the others wait — from LDS they come back in a fifth of the time of
+    // the vector L1.
     constexpr bool kLdsPerlin = (F & F_TEX_NOISE) != 0 && !LDS_TABLES;
     __shared__ __align__(16) uint32_t s_perlin[kLdsPerlin ? sizeof(DevPerlin) / 4 : 4];
     if (kLdsPerlin && a.scene.n_perlins != 0u) {
