@@ -24,6 +24,7 @@ struct RenderArgs {
     // of one step per ray (dev_pool.h); the rounds of an iteration stop when fewer than pool_stop rays are left.
     // pool_steps: node steps a lane takes on its ray per round while the ray keeps descending (1 = one step per round).
     uint32_t pool, pool_stop, pool_steps;
+    uint32_t item_counters;             // counters the persistent kernel's items are shared out to: a power of two, 1 .. kMaxItemCounters
     // The persistent kernel's work items are (pixel, chunk of chunk_spp samples): n_chunks per pixel. With
     // more than one chunk the item sums go to partial[chunk * width * height + pixel] and are added to
     // accum in chunk order by a second kernel.
@@ -37,11 +38,8 @@ struct RenderArgs {
     uint32_t count_cost;        // tally the hierarchy walks' node steps and leaf tests into the statistics (slower: not for timed launches)
 };
 enum : uint32_t { LOOP_AUTO = 0, LOOP_FUSED = 1, LOOP_QUEUE = 2 };
-#ifndef MIRT_ITEM_COUNTERS
-#define MIRT_ITEM_COUNTERS 8
-#endif
-constexpr size_t kWorkCounterBytes = MIRT_ITEM_COUNTERS * 128;  // the item counters, one per 128-byte line
-static_assert(MIRT_ITEM_COUNTERS <= 32 && (MIRT_ITEM_COUNTERS & (MIRT_ITEM_COUNTERS - 1)) == 0, "a power of two, one bit each in ItemQueue::dead");
+constexpr uint32_t kMaxItemCounters = 32;                 // one bit each in the kernel's ItemQueue::dead
+constexpr size_t kWorkCounterBytes = kMaxItemCounters * 128;  // the item counters, one per 128-byte line
 // Whether launch_render_fused() renders these arguments with the persistent pixel-queue kernel.
 bool render_uses_queue(const RenderArgs& a);
 

@@ -237,24 +237,25 @@ struct ItemQueue {
     // all wave-uniform, packed because the list kernels have no scalar registers to spare:
     uint32_t chunk_pos;  // sample chunk << 7 | slots of the wave's current tile already handed out (64: none left)
     uint32_t origin;     // that tile's origin, x | y << 16
-    uint32_t dead;       // bit i: counter i has passed its last tile (all kItemCounters bits: the launch has no work left)
+    uint32_t dead;       // bit i: counter i has passed its last tile (all of them: the launch has no work left)
 };
-// The tile runs are dealt to kItemCounters counters, each in its own 128-byte line: counter i hands out the i-th
-// contiguous share of them, in order. A wave draws from the counter of its workgroup (blockIdx mod 8) and moves on to
+// The tile runs are dealt to RenderArgs::item_counters counters, each in its own 128-byte line: counter i hands out the i-th
+// contiguous share of them, in order. A wave draws from the counter of its workgroup (blockIdx mod their number) and moves on to
 // the others when that one is exhausted. One counter for the whole device costs nothing while items are long, but
 // with almost free samples (one sphere: 0.5 M trips in 6 ms) every trip queues behind all the others'.
 // (Contiguous shares rather than every eighth run: the runs a wave takes one after the other then lie a few tile rows
 // apart instead of a sixth of the frame, the lanes it holds at any time see the same few surfaces, and fewer waves pay
 // for a branch that one lane in fifty needs — `final` +3.3 %, `random` +1.2 %, none of the scenes slower. Sixteen or
-// thirty-two shares help `final` more, +5.5 %, and cost the 10^6-sphere pass and `smoke` 1-3 %.)
-constexpr uint32_t kItemCounters = MIRT_ITEM_COUNTERS, kItemCounterStride = 32;  // stride in 32-bit words
+// thirty-two shares help `final` more, +5.5 %, and cost the 10^6-sphere pass and `smoke` 1-3 %: the host asks for
+// sixteen where iterations are heavy, eight elsewhere.)
+constexpr uint32_t kItemCounterStride = 32;  // in 32-bit words
 
 // Hands an item to every lane with `need`: pixel position and chunk; false once the launch has none left.
 // One trip to a counter fetches one wave-load. Longer runs (fixed, or a share of what is left) were measured:
 // they only pay on scenes with almost free samples, and cost 3-50 % elsewhere, because neighbouring items cost
 // alike and a wave that holds a long run of expensive ones becomes the tail of the launch.
-__device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* counters, uint32_t n_tiles, uint32_t tiles_x,
-                                           uint32_t n_chunks, uint32_t& x, uint32_t& y, uint32_t& chunk) {
+__device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* counters, uint32_t n_counters, uint32_t n_tiles,
+                                           uint32_t tiles_x, uint32_t n_chunks, uint32_t& x, uint32_t& y, uint32_t& chunk) {
     const uint32_t lane = threadIdx.x & 63u;
     bool got = false;
     for (;;) {
@@ -262,13 +263,13 @@ __device__ __forceinline__ bool take_items(bool need, ItemQueue& q, uint32_t* co
         if (m == 0) break;
         if ((q.chunk_pos & 127u) == 64u) {
             uint32_t run = 0xffffffffu;
-            for (uint32_t a = 0; a < kItemCounters && run == 0xffffffffu; ++a) {
-                const uint32_t qi = (blockIdx.x + a) & (kItemCounters - 1u);
+            for (uint32_t a = 0; a < n_counters && run == 0xffffffffu; ++a) {
+                const uint32_t qi = (blockIdx.x + a) & (n_counters - 1u);
                 if (q.dead & (1u << qi)) continue;
                 uint32_t c = 0;
                 if (lane == 0) c = atomicAdd(counters + qi * kItemCounterStride, 1u);
                 c = __builtin_amdgcn_readfirstlane(c);
-const uint32_t band = (n_tiles * n_chunks + kItemCounters - 1u) / kItemCounters;
+const uint32_t band = (n_tiles * n_chunks + n_counters - 1u) / n_counters;
                 const uint32_t r = qi * band + c;
                 if (c < band && r < n_tiles * n_chunks) run = r;
                 else q.dead |= 1u << qi;
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(kBlock, waves_for(F)) void render_queue_kernel(Rend
         for (;;) {
             if (__ballot(need) == 0) break;
             uint32_t chunk = 0, x = 0, y = 0;
-            const bool got = take_items(need, q, work_counter, n_tiles, tiles_x, n_chunks, x, y, chunk);
+            const bool got = take_items(need, q, work_counter, MIRT_ITEM_ARG(item_counters), n_tiles, tiles_x, n_chunks, x, y, chunk);
             if (need) {
                 alive = got;
                 if (alive) {
@@ -780,6 +781,8 @@ static uint32_t stack_bytes(const DevScene& s) {
 template <class Kernel, class KernelTop, class KernelPool, class KernelCount>
 static hipError_t launch_persistent(Kernel kernel, KernelTop kernel_top, KernelPool kernel_pool, KernelCount kernel_count, const RenderArgs& a_in,
                                     hipStream_t stream) {
+    // (the kernels index the counters by blockIdx masked with their number minus one)
+    if (a_in.item_counters == 0u || (a_in.item_counters & (a_in.item_counters - 1u)) != 0u || a_in.item_counters > kMaxItemCounters) return hipErrorInvalidValue;
     if ((void*)kernel_count != (void*)kernel && a_in.count_cost) return launch_persistent(kernel_count, kernel_count, kernel_count, kernel_count, a_in, stream);
     int device = 0, cus = 0, per_cu = 0;
     hipError_t e = hipGetDevice(&device);

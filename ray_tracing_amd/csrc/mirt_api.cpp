@@ -962,6 +962,14 @@ static int render_impl(mirt_ctx* c, const mirt_render_params* p, const char* who
         a.walk_budget = budget_env > 0 ? (uint32_t)budget_env : (heavy_iteration ? 96u : 48u);
         a.walk_min_lanes = lanes_env >= 0 ? (uint32_t)lanes_env : (heavy_iteration ? 8u : 24u);
         a.walk_node_lanes = node_env >= 0 ? (uint32_t)node_env : (heavy_iteration ? 8u : 16u);
+        // counters the items are shared out to (kernels.hip, take_items); MIRT_ITEM_COUNTERS for measurement runs
+        static const long counters_env = env("MIRT_ITEM_COUNTERS");
+        a.item_counters = (heavy_iteration && (c->scene.features & F_BVH)) ? 16u : 8u;
+        if (counters_env > 0) {
+            uint32_t n = 1;
+            while (n * 2u <= (uint32_t)std::min<long>(counters_env, (long)kMaxItemCounters)) n *= 2u;
+            a.item_counters = n;
+        }
         // the pooled form of the walk (MIRT_KERNEL_POOL; MIRT_POOL=0/1 overrides for A/B runs of whole programs)
         static const long pool_env = env("MIRT_POOL"), pool_stop_env = env("MIRT_POOL_STOP"), pool_steps_env = env("MIRT_POOL_STEPS");
         a.pool = pool_env >= 0 ? (pool_env ? 1u : 0u) : ((p->kernel & MIRT_KERNEL_POOL) ? 1u : 0u);
