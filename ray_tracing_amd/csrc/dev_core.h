@@ -926,6 +926,14 @@ MIRT_DEV void walk_node(const DevScene& s, float t_min, V3 rinv, V3 nc, Walk& w,
         pz = *reinterpret_cast<const float4*>(nodes + az); qz = *reinterpret_cast<const float4*>(nodes + (az ^ 16u));
         refs = *reinterpret_cast<const uint4*>(nodes + at + 96u);
     }
+#ifdef MIRT_PROBE_LOADS  // measurement builds only: what three more 16-byte loads per lane and node step cost (same line: no new data)
+    if (!(top && w.ref < s.lds_nodes)) {
+        float4 e0 = *reinterpret_cast<const float4*>(nodes + (ax ^ 16u)), e1 = *reinterpret_cast<const float4*>(nodes + (ay ^ 16u)),
+               e2 = *reinterpret_cast<const float4*>(nodes + (az ^ 16u));
+        asm volatile("" : "+v"(e0.x), "+v"(e1.x), "+v"(e2.x), "+v"(px.x), "+v"(refs.x));
+        asm volatile("" : : "v"(e0.y), "v"(e1.y), "v"(e2.y));
+    }
+#endif
     // a counting launch tallies the child boxes the node really has: its first two, and the third and fourth where
     // they exist (COUNT is a template parameter: a test of the pointer here is three instructions per step for every
     // launch — a branch on the execution mask, since the compiler cannot know the pointer is the same in all lanes)
