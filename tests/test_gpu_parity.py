@@ -769,3 +769,28 @@ def test_second_set_of_noise_tables(rt):
         del keep
     assert np.isfinite(images[0]).all() and images[0][..., :3].std() > 0.01
     assert (images[0] == images[1]).all()
+
+
+@pytest.mark.parametrize("counters", [1, 2, 32])
+def test_item_counters_do_not_enter_the_image(counters):
+    """The persistent kernel's tile runs are shared out to 8 or 16 counters, a contiguous share each
+    (MIRT_ITEM_COUNTERS overrides; read once per process, hence the child process). With one counter, two, or thirty-two
+    — more shares than some frames have tile runs, and a share boundary inside a frame of ragged size — every pixel
+    still gets each of its samples exactly once: the image equals the one-pixel-per-lane kernel's."""
+    import os, subprocess, sys
+    code = (
+        "import numpy as np, ray_tracing_amd as rt\n"
+        "for name, spp, (w, h) in (('cornell', 40, (37, 19)), ('random', 6, (64, 36)), ('final', 3, (130, 70)), ('cornell', 3, (8, 8))):\n"
+        "    sc = rt.select_scene(name); ctx = rt.Context(0); ctx.scene_upload(sc)\n"
+        "    ctx.camera_set(rt.Camera.select_camera(w / h, name))\n"
+        "    out = []\n"
+        "    for k in (rt.KERNEL_FUSED, rt.KERNEL_QUEUE):\n"
+        "        ctx.frame_begin(w, h); ctx.render(spp, 50, seed=4, kernel=k); st = ctx.stats(); assert st['device_faults'] == 0\n"
+        "        out.append((ctx.read_accum(), st['segments']))\n"
+        "    np.testing.assert_allclose(out[1][0], out[0][0], rtol=2e-6, atol=1e-6)\n"
+        "    assert out[1][1] == out[0][1] and (out[1][0][..., 3] == spp).all()\n"
+        "print('ok')\n")
+    env = dict(os.environ, MIRT_ITEM_COUNTERS=str(counters))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
