@@ -295,8 +295,10 @@ const uint32_t band = (n_tiles * n_chunks + n_counters - 1u) / n_counters;
 }
 
 // TOP_NODES: the hierarchies' nodes nearest the roots are copied to LDS behind the stacks and fetched from there
-// (walk_node). Launched only where most of the scene's nodes fit (launch_persistent): the second fetch path in the
-// node step costs 2-4 % by itself and pays when few steps need it.
+// (walk_node). Launched wherever at least a root and its children fit (launch_persistent): every walk starts with
+// them, and the second fetch path in the node step costs next to nothing since it is a branch of LDS reads (while the
+// compiler merged it with the global fetches into flat loads it cost 2-4 %, and the form was kept to scenes most of
+// whose nodes fit). The 10^6-sphere scene has room for seven nodes beside its stacks: +1.4 % at 4 spp, even at 1 spp.
 // POOL: the hierarchy walks of the workgroup's 256 lanes advance together in LDS (dev_pool.h) instead of lane by lane.
 // COUNT: the hierarchy walks tally their node steps and leaf tests (a.count_cost launches; a form of its own so that the
 // timed form carries neither the tallies nor a test for them in its node step).
@@ -817,7 +819,7 @@ static hipError_t launch_persistent(Kernel kernel, KernelTop kernel_top, KernelP
         if (room > 0) lds_nodes = (uint32_t)std::min<long>(room / (long)kLdsNodeStride, (long)a.scene.lds_nodes);
         static const long lds_env = [] { const char* ev = std::getenv("MIRT_LDS_NODES"); return ev ? std::atol(ev) : -1l; }();
         if (lds_env >= 0) lds_nodes = std::min(lds_nodes, (uint32_t)lds_env);
-        else if (2u * lds_nodes < a.scene.lds_nodes) lds_nodes = 0;
+        else if (lds_nodes < 5u && lds_nodes < a.scene.lds_nodes) lds_nodes = 0;  // (less than a root and its children: not worth the form)
         if (lds_nodes && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&with_nodes, kernel_top, kBlock, stack_bytes(a.scene) + lds_nodes * kLdsNodeStride) != hipSuccess ||
                           with_nodes < per_cu))
             lds_nodes = 0;
